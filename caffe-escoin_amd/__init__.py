@@ -1,0 +1,230 @@
+"""caffe-escoin_amd: MI355X-native direct sparse convolution forward (Escoin's SCONV path).
+
+The product is the C-ABI shared library ``libescoin_hip.so`` (hand-written HIP kernels for
+gfx950, see ``csrc/`` and ``include/escoin.h``) plus the C++ Caffe-compatible Layer/Blob shim
+in ``caffe_shim/``.  This Python module is only a ctypes binding of that C ABI, used by the
+tests and ``bench.py``; torch supplies device memory, streams and ``torch.distributed`` --
+plumbing, not the product.
+
+There is no CPU fallback: if the library is missing or no HIP device is visible the compute
+entry points raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import shard, synth  # noqa: F401  (re-exported)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libescoin_hip.so")
+
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
+CONV_MODE_SCONV, CONV_MODE_SCONV_PAR = 2, 3
+
+# every symbol include/escoin.h declares (tests check the library exports all of them)
+API_SYMBOLS = [
+    "escoin_last_error", "escoin_device_count", "escoin_out_shape", "escoin_padded_len",
+    "escoin_plan_create", "escoin_plan_destroy", "escoin_plan_set_option",
+    "escoin_weight_align", "escoin_plan_set_csr", "escoin_plan_nnz", "escoin_plan_get_csr",
+    "escoin_plan_workspace_bytes", "escoin_plan_kernel_name", "escoin_forward",
+    "escoin_gpu_sconv", "escoin_gpu_stretch", "escoin_copy_input_data",
+    "escoin_gpu_sparse_dense2csr",
+]
+
+
+class EscoinError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """Mirror of escoin_conv_desc (include/escoin.h)."""
+    _fields_ = [(n, C.c_int) for n in
+                ("N", "C", "H", "W", "M", "KH", "KW", "pad_h", "pad_w", "stride_h", "stride_w",
+                 "dil_h", "dil_w", "group", "has_bias", "fuse_relu")]
+
+    @classmethod
+    def from_shape(cls, s, N=None, fuse_relu=False):
+        """From a synth.ConvShape."""
+        return cls(s.N if N is None else N, s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w,
+                   s.stride_h, s.stride_w, s.dil_h, s.dil_w, s.group, int(bool(s.bias)),
+                   int(bool(fuse_relu)))
+
+
+def build(verbose=False):
+    """Compile libescoin_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], stdout=out)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EscoinError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                          " (there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip, cp = C.c_void_p, C.c_int, C.c_char_p
+    dp = C.POINTER(ConvDesc)
+    L.escoin_last_error.restype = cp
+    L.escoin_last_error.argtypes = []
+    L.escoin_device_count.restype = ip
+    L.escoin_device_count.argtypes = []
+    L.escoin_out_shape.restype = ip
+    L.escoin_out_shape.argtypes = [dp, C.POINTER(ip), C.POINTER(ip)]
+    L.escoin_padded_len.restype = C.c_long
+    L.escoin_padded_len.argtypes = [dp]
+    L.escoin_plan_create.restype = ip
+    L.escoin_plan_create.argtypes = [dp, C.POINTER(vp)]
+    L.escoin_plan_destroy.restype = ip
+    L.escoin_plan_destroy.argtypes = [vp]
+    L.escoin_plan_set_option.restype = ip
+    L.escoin_plan_set_option.argtypes = [vp, cp, ip]
+    L.escoin_weight_align.restype = ip
+    L.escoin_weight_align.argtypes = [vp, vp, ip, vp]
+    L.escoin_plan_set_csr.restype = ip
+    L.escoin_plan_set_csr.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.escoin_plan_nnz.restype = C.c_long
+    L.escoin_plan_nnz.argtypes = [vp, ip]
+    L.escoin_plan_get_csr.restype = ip
+    L.escoin_plan_get_csr.argtypes = [vp, vp, vp, vp, ip]
+    L.escoin_plan_workspace_bytes.restype = C.c_size_t
+    L.escoin_plan_workspace_bytes.argtypes = [vp]
+    L.escoin_plan_kernel_name.restype = cp
+    L.escoin_plan_kernel_name.argtypes = [vp]
+    L.escoin_forward.restype = ip
+    L.escoin_forward.argtypes = [vp, vp, vp, vp, ip, vp]
+    L.escoin_gpu_sconv.restype = ip
+    L.escoin_gpu_sconv.argtypes = [ip, ip, vp, ip, vp, vp, vp, vp] + [ip] * 10 + [vp, ip, ip, vp]
+    L.escoin_gpu_stretch.restype = ip
+    L.escoin_gpu_stretch.argtypes = [vp, vp] + [ip] * 7 + [vp]
+    L.escoin_copy_input_data.restype = ip
+    L.escoin_copy_input_data.argtypes = [vp, vp] + [ip] * 5 + [vp]
+    L.escoin_gpu_sparse_dense2csr.restype = ip
+    L.escoin_gpu_sparse_dense2csr.argtypes = [ip, ip, vp, vp, vp, vp, vp, C.POINTER(ip), vp]
+    _lib = L
+    return L
+
+
+def check(rc, what="escoin call"):
+    if rc != 0:
+        raise EscoinError("%s failed (%d): %s" % (what, rc, lib().escoin_last_error().decode()))
+
+
+def device_count():
+    return lib().escoin_device_count()
+
+
+def out_shape(desc):
+    oh, ow = C.c_int(), C.c_int()
+    check(lib().escoin_out_shape(C.byref(desc), C.byref(oh), C.byref(ow)), "escoin_out_shape")
+    return oh.value, ow.value
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Plan(object):
+    """escoin_plan: one ConvolutionLayer's sparse state (CSR + weight streams) on one device."""
+
+    def __init__(self, desc, kernel=KERNEL_AUTO, conv_mode=CONV_MODE_SCONV_PAR):
+        self.desc = desc
+        self._h = C.c_void_p()
+        check(lib().escoin_plan_create(C.byref(desc), C.byref(self._h)), "escoin_plan_create")
+        if kernel != KERNEL_AUTO:
+            self.set_option("kernel", kernel)
+        if conv_mode != CONV_MODE_SCONV_PAR:
+            self.set_option("conv_mode", conv_mode)
+        self.out_hw = out_shape(desc)
+
+    def close(self):
+        if self._h:
+            lib().escoin_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        check(lib().escoin_plan_set_option(self._h, key.encode(), int(value)),
+              "escoin_plan_set_option(%s)" % key)
+
+    def weight_align(self, dense_w, stream=None):
+        """WeightAlign().  dense_w: numpy (host) or torch CUDA tensor (device), M x C/g x KH x KW."""
+        if isinstance(dense_w, np.ndarray):
+            w = np.ascontiguousarray(dense_w, np.float32)
+            check(lib().escoin_weight_align(self._h, _np_ptr(w), 0, stream), "escoin_weight_align")
+        else:
+            w = dense_w.contiguous()
+            assert w.is_cuda and w.dtype.is_floating_point and w.element_size() == 4
+            check(lib().escoin_weight_align(self._h, C.c_void_p(w.data_ptr()), 1, stream),
+                  "escoin_weight_align")
+
+    def set_csr(self, rowptr, colidx, values, nnz_per_group, stream=None):
+        rp = np.ascontiguousarray(rowptr, np.int32)
+        ci = np.ascontiguousarray(colidx, np.int32)
+        va = np.ascontiguousarray(values, np.float32)
+        ng = np.ascontiguousarray(nnz_per_group, np.int32)
+        check(lib().escoin_plan_set_csr(self._h, _np_ptr(rp), _np_ptr(ci), _np_ptr(va), _np_ptr(ng),
+                                        stream), "escoin_plan_set_csr")
+
+    def nnz(self, group=-1):
+        n = lib().escoin_plan_nnz(self._h, group)
+        if n < 0:
+            check(int(n), "escoin_plan_nnz")
+        return int(n)
+
+    def get_csr(self, stretched=False):
+        d = self.desc
+        mg = d.M // d.group
+        nnz = self.nnz()
+        rp = np.zeros(d.group * (mg + 1), np.int32)
+        ci = np.zeros(max(nnz, 1), np.int32)
+        va = np.zeros(max(nnz, 1), np.float32)
+        check(lib().escoin_plan_get_csr(self._h, _np_ptr(rp), _np_ptr(ci), _np_ptr(va),
+                                        int(stretched)), "escoin_plan_get_csr")
+        ng = np.array([self.nnz(g) for g in range(d.group)], np.int32)
+        return rp, ci[:nnz], va[:nnz], ng
+
+    @property
+    def workspace_bytes(self):
+        return int(lib().escoin_plan_workspace_bytes(self._h))
+
+    @property
+    def kernel_name(self):
+        return lib().escoin_plan_kernel_name(self._h).decode()
+
+    def forward_ptr(self, bottom_ptr, bias_ptr, top_ptr, n_images, stream=None):
+        """Raw-pointer Forward_gpu (device pointers as ints)."""
+        check(lib().escoin_forward(self._h, C.c_void_p(bottom_ptr),
+                                   C.c_void_p(bias_ptr) if bias_ptr else None,
+                                   C.c_void_p(top_ptr), int(n_images), stream), "escoin_forward")
+
+    def forward(self, bottom, bias=None, top=None):
+        """Forward_gpu on torch CUDA tensors, on torch's current stream."""
+        import torch
+        d = self.desc
+        assert bottom.is_cuda and bottom.dtype == torch.float32 and bottom.is_contiguous()
+        n = bottom.shape[0]
+        assert tuple(bottom.shape[1:]) == (d.C, d.H, d.W), "bottom shape mismatch"
+        if top is None:
+            top = torch.empty((n, d.M) + tuple(self.out_hw), device=bottom.device,
+                              dtype=torch.float32)
+        assert top.is_contiguous() and tuple(top.shape) == (n, d.M) + tuple(self.out_hw)
+        if bias is not None:
+            assert bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == d.M
+        stream = C.c_void_p(torch.cuda.current_stream(bottom.device).cuda_stream)
+        self.forward_ptr(bottom.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                         top.data_ptr(), n, stream)
+        return top

@@ -1,0 +1,305 @@
+// escoin_capi.hip -- host side of the C ABI declared in include/escoin.h:
+// plan life cycle, WeightAlign (dense -> CSR -> device weight streams), dispatch.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "escoin_plan.h"
+
+namespace escoin {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+static int out_dim(int in, int k, int pad, int stride, int dil) {
+  // conv_layer.cpp:16-19
+  return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1;
+}
+
+static int validate(const escoin_conv_desc *d, Geometry *g) {
+  if (!d) return fail(ESCOIN_EINVAL, "null descriptor");
+  if (d->N < 1 || d->C < 1 || d->H < 1 || d->W < 1 || d->M < 1 || d->KH < 1 || d->KW < 1)
+    return fail(ESCOIN_EINVAL, "non-positive dimension");
+  if (d->pad_h < 0 || d->pad_w < 0 || d->stride_h < 1 || d->stride_w < 1 || d->dil_h < 1 ||
+      d->dil_w < 1 || d->group < 1)
+    return fail(ESCOIN_EINVAL, "bad pad/stride/dilation/group");
+  // base_conv_layer.cpp:393-396: channels_ % group_ == 0, num_output_ % group_ == 0
+  if (d->C % d->group != 0) return fail(ESCOIN_EINVAL, "channels not divisible by group");
+  if (d->M % d->group != 0) return fail(ESCOIN_EINVAL, "num_output not divisible by group");
+  if (d->KH > 255 || d->KW > 255 || d->C / d->group > 32767)
+    return fail(ESCOIN_EINVAL, "kernel > 255 or > 32767 channels per group not supported");
+  const int oh = out_dim(d->H, d->KH, d->pad_h, d->stride_h, d->dil_h);
+  const int ow = out_dim(d->W, d->KW, d->pad_w, d->stride_w, d->dil_w);
+  if (oh < 1 || ow < 1) return fail(ESCOIN_EINVAL, "empty output (kernel larger than padded input)");
+  if (g) {
+    g->d = *d;
+    g->OH = oh;
+    g->OW = ow;
+    g->Cg = d->C / d->group;
+    g->Mg = d->M / d->group;
+    g->kdim = g->Cg * d->KH * d->KW;
+  }
+  return ESCOIN_OK;
+}
+
+static void free_device(escoin_plan *p) {
+  if (p->d_rowptr) (void)hipFree(p->d_rowptr);
+  if (p->d_taps) (void)hipFree(p->d_taps);
+  if (p->d_vals) (void)hipFree(p->d_vals);
+  if (p->d_stream) (void)hipFree(p->d_stream);
+  if (p->d_stream_ptr) (void)hipFree(p->d_stream_ptr);
+  p->d_rowptr = p->d_taps = p->d_stream_ptr = nullptr;
+  p->d_vals = nullptr;
+  p->d_stream = nullptr;
+  p->device_bytes = 0;
+}
+
+// Uploads the CSR held in p->rowptr/colidx/values and builds the kernel-specific
+// streams.  Shared tail of escoin_weight_align and escoin_plan_set_csr.
+static int upload(escoin_plan *p, hipStream_t stream) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(ESCOIN_ENODEVICE, "no HIP device: this library has no CPU fallback");
+  ESCOIN_HIP_TRY(hipGetDevice(&p->device));
+  free_device(p);
+  const Geometry &g = p->g;
+  long nnz = 0;
+  for (int grp = 0; grp < g.d.group; ++grp) nnz += (long)p->colidx[grp].size();
+  std::vector<int> rowptr(g.d.M + 1), taps((size_t)(nnz > 0 ? nnz : 1));
+  std::vector<float> vals((size_t)(nnz > 0 ? nnz : 1));
+  long base = 0;
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    for (int m = 0; m < g.Mg; ++m) rowptr[grp * g.Mg + m] = (int)(base + p->rowptr[grp][m]);
+    const long n_g = (long)p->colidx[grp].size();
+    for (long j = 0; j < n_g; ++j) {
+      const int col = p->colidx[grp][j];
+      const int kc = col % g.d.KW, kr = (col / g.d.KW) % g.d.KH, ic = col / (g.d.KW * g.d.KH);
+      taps[base + j] = pack_tap(ic, kr, kc);
+      vals[base + j] = p->values[grp][j];
+    }
+    base += n_g;
+  }
+  rowptr[g.d.M] = (int)base;
+  ESCOIN_HIP_TRY(hipMalloc(&p->d_rowptr, sizeof(int) * rowptr.size()));
+  ESCOIN_HIP_TRY(hipMalloc(&p->d_taps, sizeof(int) * taps.size()));
+  ESCOIN_HIP_TRY(hipMalloc(&p->d_vals, sizeof(float) * vals.size()));
+  p->device_bytes += sizeof(int) * (rowptr.size() + taps.size()) + sizeof(float) * vals.size();
+  ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_rowptr, rowptr.data(), sizeof(int) * rowptr.size(),
+                                hipMemcpyHostToDevice, stream));
+  ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_taps, taps.data(), sizeof(int) * taps.size(),
+                                hipMemcpyHostToDevice, stream));
+  ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_vals, vals.data(), sizeof(float) * vals.size(),
+                                hipMemcpyHostToDevice, stream));
+  ESCOIN_HIP_TRY(hipStreamSynchronize(stream));  // host vectors die at scope exit
+
+  p->tiled = TiledConfig();
+  const bool want_tiled = p->kernel_choice == ESCOIN_KERNEL_TILED ||
+                          (p->kernel_choice == ESCOIN_KERNEL_AUTO && tiled_supported(g));
+  if (want_tiled) {
+    if (!tiled_supported(g))
+      return fail(ESCOIN_EINVAL, "tiled kernel requested for a geometry it does not support");
+    int rc = tiled_build(p, stream);
+    if (rc != ESCOIN_OK) return rc;
+  }
+  p->kernel_name = p->tiled.enabled ? tiled_kernel_name(p) : generic_kernel_name(g.d.fuse_relu != 0);
+  p->aligned = true;
+  return ESCOIN_OK;
+}
+
+}  // namespace escoin
+
+using namespace escoin;
+
+extern "C" {
+
+const char *escoin_last_error(void) { return g_last_error.c_str(); }
+
+int escoin_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int escoin_out_shape(const escoin_conv_desc *desc, int *out_h, int *out_w) {
+  Geometry g;
+  int rc = validate(desc, &g);
+  if (rc != ESCOIN_OK) return rc;
+  if (out_h) *out_h = g.OH;
+  if (out_w) *out_w = g.OW;
+  return ESCOIN_OK;
+}
+
+long escoin_padded_len(const escoin_conv_desc *d) {
+  if (!d) return fail(ESCOIN_EINVAL, "null descriptor");
+  // base_conv_layer.cpp:71
+  return (long)d->C * (d->H + d->pad_h) * (d->W + d->pad_w) + (long)d->pad_h * (d->W + 2 * d->pad_w);
+}
+
+int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan) {
+  if (!plan) return fail(ESCOIN_EINVAL, "null plan pointer");
+  *plan = nullptr;
+  Geometry g;
+  int rc = validate(desc, &g);
+  if (rc != ESCOIN_OK) return rc;
+  escoin_plan *p = new (std::nothrow) escoin_plan();
+  if (!p) return fail(ESCOIN_ENOMEM, "out of host memory");
+  p->g = g;
+  p->rowptr.assign(g.d.group, std::vector<int>(g.Mg + 1, 0));
+  p->colidx.assign(g.d.group, std::vector<int>());
+  p->values.assign(g.d.group, std::vector<float>());
+  *plan = p;
+  return ESCOIN_OK;
+}
+
+int escoin_plan_destroy(escoin_plan *plan) {
+  if (!plan) return ESCOIN_OK;
+  free_device(plan);
+  delete plan;
+  return ESCOIN_OK;
+}
+
+int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
+  if (!p || !key) return fail(ESCOIN_EINVAL, "null argument");
+  if (p->aligned) return fail(ESCOIN_ESTATE, "options must be set before weight_align/set_csr");
+  if (!strcmp(key, "kernel")) {
+    if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_TILED)
+      return fail(ESCOIN_EINVAL, "unknown kernel id");
+    p->kernel_choice = value;
+  } else if (!strcmp(key, "conv_mode")) {
+    if (value != ESCOIN_CONV_MODE_SCONV && value != ESCOIN_CONV_MODE_SCONV_PAR)
+      return fail(ESCOIN_EINVAL,
+                  "only conv_mode SCONV (2) and SCONV_PAR (3) are served by this library");
+    p->conv_mode = value;
+  } else if (!strcmp(key, "dense_gate")) {
+    p->dense_gate = value != 0;
+  } else {
+    return fail(ESCOIN_EINVAL, std::string("unknown option: ") + key);
+  }
+  return ESCOIN_OK;
+}
+
+int escoin_weight_align(escoin_plan *p, const float *dense_w, int w_on_device, void *stream) {
+  if (!p || !dense_w) return fail(ESCOIN_EINVAL, "null argument");
+  const Geometry &g = p->g;
+  const size_t count = (size_t)g.d.M * g.kdim;
+  std::vector<float> host;
+  const float *w = dense_w;
+  if (w_on_device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+      return fail(ESCOIN_ENODEVICE, "no HIP device: cannot read device weights");
+    host.resize(count);
+    ESCOIN_HIP_TRY(hipMemcpyAsync(host.data(), dense_w, sizeof(float) * count,
+                                  hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ESCOIN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    w = host.data();
+  }
+  // caffe_cpu_sparse_dense2csr, math_functions.cpp:92-105: row-major scan, keep != 0
+  const size_t weight_offset = (size_t)g.Mg * g.kdim;  // base_conv_layer.cpp:60
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    std::vector<int> &rp = p->rowptr[grp];
+    std::vector<int> &ci = p->colidx[grp];
+    std::vector<float> &va = p->values[grp];
+    rp.assign(g.Mg + 1, 0);
+    ci.clear();
+    va.clear();
+    const float *A = w + weight_offset * grp;
+    for (int i = 0; i < g.Mg; ++i) {
+      for (int j = 0; j < g.kdim; ++j) {
+        const float v = A[(size_t)i * g.kdim + j];
+        if (v != 0) {
+          va.push_back(v);
+          ci.push_back(j);
+        }
+      }
+      rp[i + 1] = (int)ci.size();
+    }
+  }
+  p->aligned = false;
+  return upload(p, (hipStream_t)stream);
+}
+
+int escoin_plan_set_csr(escoin_plan *p, const int *rowptr, const int *colidx, const float *values,
+                        const int *nnz_per_group, void *stream) {
+  if (!p || !rowptr || !nnz_per_group) return fail(ESCOIN_EINVAL, "null argument");
+  const Geometry &g = p->g;
+  long base = 0;
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    const int n_g = nnz_per_group[grp];
+    const int *rp = rowptr + (size_t)grp * (g.Mg + 1);
+    if (n_g < 0 || rp[0] != 0 || rp[g.Mg] != n_g)
+      return fail(ESCOIN_EINVAL, "set_csr: rowptr does not match nnz_per_group");
+    if (n_g > 0 && (!colidx || !values)) return fail(ESCOIN_EINVAL, "set_csr: null colidx/values");
+    for (int m = 0; m < g.Mg; ++m)
+      if (rp[m + 1] < rp[m]) return fail(ESCOIN_EINVAL, "set_csr: rowptr not monotone");
+    for (int j = 0; j < n_g; ++j)
+      if (colidx[base + j] < 0 || colidx[base + j] >= g.kdim)
+        return fail(ESCOIN_EINVAL, "set_csr: column index out of range");
+    p->rowptr[grp].assign(rp, rp + g.Mg + 1);
+    p->colidx[grp].assign(colidx + base, colidx + base + n_g);
+    p->values[grp].assign(values + base, values + base + n_g);
+    base += n_g;
+  }
+  p->aligned = false;
+  return upload(p, (hipStream_t)stream);
+}
+
+long escoin_plan_nnz(const escoin_plan *p, int group) {
+  if (!p) return fail(ESCOIN_EINVAL, "null plan");
+  if (group >= p->g.d.group) return fail(ESCOIN_EINVAL, "group out of range");
+  if (group >= 0) return (long)p->colidx[group].size();
+  long n = 0;
+  for (const auto &c : p->colidx) n += (long)c.size();
+  return n;
+}
+
+int escoin_plan_get_csr(const escoin_plan *p, int *rowptr, int *colidx, float *values,
+                        int stretched) {
+  if (!p || !rowptr) return fail(ESCOIN_EINVAL, "null argument");
+  const Geometry &g = p->g;
+  long base = 0;
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    memcpy(rowptr + (size_t)grp * (g.Mg + 1), p->rowptr[grp].data(), sizeof(int) * (g.Mg + 1));
+    const long n_g = (long)p->colidx[grp].size();
+    for (long j = 0; j < n_g; ++j) {
+      int col = p->colidx[grp][j];
+      if (stretched) {  // base_conv_layer.cpp:99-105
+        const int kc = col % g.d.KW, kr = (col / g.d.KW) % g.d.KH, ic = col / (g.d.KW * g.d.KH);
+        col = (ic * (g.d.H + g.d.pad_h) + kr) * (g.d.W + g.d.pad_w) + kc;
+      }
+      if (colidx) colidx[base + j] = col;
+      if (values) values[base + j] = p->values[grp][j];
+    }
+    base += n_g;
+  }
+  return ESCOIN_OK;
+}
+
+size_t escoin_plan_workspace_bytes(const escoin_plan *p) { return p ? p->device_bytes : 0; }
+
+const char *escoin_plan_kernel_name(const escoin_plan *p) {
+  return p ? p->kernel_name.c_str() : "";
+}
+
+int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_dev, float *top_dev,
+                   int n_images, void *stream) {
+  if (!p || !bottom_dev || !top_dev) return fail(ESCOIN_EINVAL, "null argument");
+  if (!p->aligned) return fail(ESCOIN_ESTATE, "forward called before weight_align / set_csr");
+  if (n_images < 0 || n_images > p->g.d.N)
+    return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
+  if (n_images == 0) return ESCOIN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (p->tiled.enabled) return launch_tiled(p, bottom_dev, bias_dev, top_dev, n_images, s);
+  return launch_generic(p, bottom_dev, bias_dev, top_dev, n_images, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Internal plan structure of libescoin_hip.so (not part of the C ABI).
+#ifndef ESCOIN_PLAN_H_
+#define ESCOIN_PLAN_H_
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "escoin.h"
+
+namespace escoin {
+
+// Thread-local error message behind escoin_last_error().
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define ESCOIN_HIP_TRY(expr)                                                          \
+  do {                                                                                \
+    hipError_t e__ = (expr);                                                          \
+    if (e__ != hipSuccess)                                                            \
+      return ::escoin::fail(ESCOIN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+// A nonzero's kernel tap packed for the generic kernel: ic << 16 | kr << 8 | kc
+// (ic group-local).
+inline int pack_tap(int ic, int kr, int kc) { return (ic << 16) | (kr << 8) | kc; }
+
+struct Geometry {
+  escoin_conv_desc d;
+  int OH, OW;
+  int Cg, Mg;   // channels per group
+  int kdim;     // kernel_dim_ = Cg*KH*KW
+};
+
+// Parameters of the tiled kernel chosen in weight_align (see sconv_tiled.hip).
+struct TiledConfig {
+  bool enabled = false;
+  int s4 = 0;          // quads (4 floats) per LDS row, power of two
+  int kw_classes = 0;  // KW
+  int tile_rows = 0;   // output rows (over the flattened (image,row) axis) per workgroup
+  int imgs_per_wg = 0; // whole images per workgroup (0: row bands of one image)
+  int pix_waves = 0;   // waves along the pixel axis
+  int oc_waves = 0;    // waves along the output-channel axis
+  int G = 0;           // output channels per wave
+  int icb = 0;         // input channels per LDS block
+  int n_icb = 0;       // blocks per group
+  int slots = 0;       // records per row group in the weight stream
+  size_t lds_bytes = 0;
+};
+
+}  // namespace escoin
+
+struct escoin_plan {
+  escoin::Geometry g;
+  int kernel_choice = ESCOIN_KERNEL_AUTO;
+  int conv_mode = ESCOIN_CONV_MODE_SCONV_PAR;
+  int dense_gate = 0;
+  bool aligned = false;
+  int device = -1;
+
+  // host CSR, per group (unstretched column indices), exactly what
+  // caffe_cpu_sparse_dense2csr produces (math_functions.cpp:92-105)
+  std::vector<std::vector<int>> rowptr;   // [group][Mg+1]
+  std::vector<std::vector<int>> colidx;   // [group][nnz_g]
+  std::vector<std::vector<float>> values; // [group][nnz_g]
+
+  // device arrays for the generic kernel
+  int *d_rowptr = nullptr;   // [M+1] absolute offsets into d_taps/d_vals
+  int *d_taps = nullptr;     // [nnz] packed (ic,kr,kc)
+  float *d_vals = nullptr;   // [nnz]
+
+  // device arrays for the tiled kernel
+  escoin::TiledConfig tiled;
+  unsigned *d_stream = nullptr;   // row-grouped weight stream
+  int *d_stream_ptr = nullptr;    // per (oc-wave-group, ic-block) offsets into d_stream
+  size_t stream_words = 0;
+
+  size_t device_bytes = 0;
+  std::string kernel_name = "(not aligned)";
+};
+
+namespace escoin {
+
+// sconv_generic.hip
+int launch_generic(const escoin_plan *p, const float *bottom, const float *bias, float *top,
+                   int n_images, hipStream_t stream);
+const char *generic_kernel_name(bool relu);
+
+// sconv_tiled.hip
+bool tiled_supported(const Geometry &g);
+int tiled_build(escoin_plan *p, hipStream_t stream);  // fills p->tiled, uploads streams
+int launch_tiled(const escoin_plan *p, const float *bottom, const float *bias, float *top,
+                 int n_images, hipStream_t stream);
+const char *tiled_kernel_name(const escoin_plan *p);
+
+}  // namespace escoin
+
+#endif  // ESCOIN_PLAN_H_

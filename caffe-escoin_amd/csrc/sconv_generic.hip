@@ -1,0 +1,301 @@
+// sconv_generic.hip -- gfx950 kernels that work for ANY geometry (stride, dilation,
+// groups, non-square) and keep the reference's summation order.
+//
+//   escoin_sconv_generic_kernel   plan path: reads the dense NCHW bottom directly (the
+//       halo is a bounds test, no padded copy: removes the reference's extra HBM round
+//       trip, base_conv_layer.cpp:771,823-830), one lane = one output pixel, the wave
+//       walks its output channel's CSR row with scalar loads (value / packed tap are
+//       wave-uniform), accumulating with one fmaf per nonzero from 0 in CSR order --
+//       the loop nest of caffe_cpu_sconv (math_functions.cpp:162-174), so the result is
+//       bit-identical to the reference CPU path.  Bias is added once afterwards
+//       (conv_layer.cpp:55-58) in the same kernel; optional ReLU.
+//
+//   escoin_sconv_padded_kernel    math_functions-level drop-in for caffe_gpu_sconv
+//       (math_functions.cu:590-704) on the reference's own padded layout + stretched CSR.
+//
+//   stretch / copy_input / dense2csr helpers (math_functions.cu:706-766, 103-152).
+//
+// wave = 64 lanes; blocks are (64, WAVES_PER_BLOCK): threadIdx.y is the wave id, so
+// everything derived from it is wave-uniform and lives in SGPRs.
+#include <hip/hip_runtime.h>
+
+#include "escoin_plan.h"
+
+namespace escoin {
+
+constexpr int kWavesPerBlock = 4;
+
+struct GenericArgs {
+  const float *__restrict__ in;
+  float *__restrict__ out;
+  const int *__restrict__ rowptr;
+  const int *__restrict__ taps;
+  const float *__restrict__ vals;
+  const float *__restrict__ bias;
+  int C, H, W, M, OH, OW;
+  int pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
+  int Cg, Mg;
+};
+
+template <bool RELU>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+escoin_sconv_generic_kernel(GenericArgs a) {
+  const int lane = threadIdx.x;
+  const int oc = __builtin_amdgcn_readfirstlane(blockIdx.y * kWavesPerBlock + threadIdx.y);
+  if (oc >= a.M) return;
+  const int n = blockIdx.z;
+  const int p = blockIdx.x * 64 + lane;
+  const int npix = a.OH * a.OW;
+  const bool live = p < npix;
+  const int oh = live ? p / a.OW : 0;
+  const int ow = live ? p - oh * a.OW : 0;
+  const int ih0 = oh * a.stride_h - a.pad_h;
+  const int iw0 = ow * a.stride_w - a.pad_w;
+  const int grp = oc / a.Mg;
+  const float *__restrict__ img = a.in + ((size_t)n * a.C + (size_t)grp * a.Cg) * a.H * a.W;
+  const int jb = a.rowptr[oc], je = a.rowptr[oc + 1];
+  float sum = 0.f;
+  for (int j = jb; j < je; ++j) {
+    const int tap = a.taps[j];
+    const float v = a.vals[j];
+    const int ic = tap >> 16, kr = (tap >> 8) & 0xff, kc = tap & 0xff;
+    const int ih = ih0 + kr * a.dil_h;
+    const int iw = iw0 + kc * a.dil_w;
+    float x = 0.f;
+    if (live && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+      x = img[((size_t)ic * a.H + ih) * a.W + iw];
+    sum = fmaf(v, x, sum);
+  }
+  if (a.bias) sum += a.bias[oc];
+  if (RELU) sum = fmaxf(sum, 0.f);
+  if (live) a.out[((size_t)n * a.M + oc) * npix + p] = sum;
+}
+
+const char *generic_kernel_name(bool relu) {
+  return relu ? "escoin_sconv_generic_kernel<true>" : "escoin_sconv_generic_kernel<false>";
+}
+
+int launch_generic(const escoin_plan *p, const float *bottom, const float *bias, float *top,
+                   int n_images, hipStream_t stream) {
+  const Geometry &g = p->g;
+  GenericArgs a;
+  a.in = bottom;
+  a.out = top;
+  a.rowptr = p->d_rowptr;
+  a.taps = p->d_taps;
+  a.vals = p->d_vals;
+  a.bias = bias;
+  a.C = g.d.C; a.H = g.d.H; a.W = g.d.W; a.M = g.d.M; a.OH = g.OH; a.OW = g.OW;
+  a.pad_h = g.d.pad_h; a.pad_w = g.d.pad_w; a.stride_h = g.d.stride_h; a.stride_w = g.d.stride_w;
+  a.dil_h = g.d.dil_h; a.dil_w = g.d.dil_w; a.Cg = g.Cg; a.Mg = g.Mg;
+  const int npix = g.OH * g.OW;
+  dim3 block(64, kWavesPerBlock, 1);
+  dim3 grid((npix + 63) / 64, (g.d.M + kWavesPerBlock - 1) / kWavesPerBlock, n_images);
+  if (grid.y > 65535u || grid.z > 65535u)
+    return fail(ESCOIN_EINVAL, "generic kernel: grid dimension exceeds 65535");
+  if (g.d.fuse_relu)
+    hipLaunchKernelGGL(escoin_sconv_generic_kernel<true>, grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL(escoin_sconv_generic_kernel<false>, grid, block, 0, stream, a);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  return ESCOIN_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// math_functions-level drop-ins
+// ------------------------------------------------------------------------------------
+
+struct PaddedArgs {
+  const float *__restrict__ in;
+  float *__restrict__ out;
+  const int *__restrict__ rowptr;
+  const int *__restrict__ colidx;
+  const float *__restrict__ vals;
+  const float *__restrict__ bias;
+  int H, W, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
+  int OH, OW, num_oc;
+  long in_stride;   // floats between consecutive images of the padded input
+  long out_stride;  // floats between consecutive images of the output
+};
+
+// One lane = one output pixel of (image n, channel oc); same arithmetic as
+// caffe_cpu_sconv incl. the dilated branch's index decode (math_functions.cpp:142-160).
+template <bool RELU, bool DILATED>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+escoin_sconv_padded_kernel(PaddedArgs a) {
+  const int lane = threadIdx.x;
+  const int oc = __builtin_amdgcn_readfirstlane(blockIdx.y * kWavesPerBlock + threadIdx.y);
+  if (oc >= a.num_oc) return;
+  const int n = blockIdx.z;
+  const int npix = a.OH * a.OW;
+  const int p = blockIdx.x * 64 + lane;
+  const bool live = p < npix;
+  const int oh = live ? p / a.OW : 0;
+  const int ow = live ? p - oh * a.OW : 0;
+  const int PW = a.W + a.pad_w, PH = a.H + a.pad_h;
+  const float *__restrict__ img = a.in + (size_t)n * a.in_stride;
+  const float *__restrict__ base = img + (size_t)oh * a.stride_h * PW + ow * a.stride_w;
+  float sum = RELU ? a.bias[oc] : 0.f;  // math_functions.cu:215,421 vs :282
+  for (int j = a.rowptr[oc]; j < a.rowptr[oc + 1]; ++j) {
+    const int col = a.colidx[j];
+    const float v = a.vals[j];
+    float x;
+    if (DILATED) {
+      const int kc = col % PW, kr = (col / PW) % PH, ic = col / (PW * PH);
+      x = img[((size_t)ic * PH + kr * a.dil_h + oh * a.stride_h) * PW + kc * a.dil_w +
+              ow * a.stride_w];
+    } else {
+      x = base[col];
+    }
+    sum = fmaf(v, x, sum);
+  }
+  if (RELU) sum = fmaxf(sum, 0.f);
+  if (live) a.out[(size_t)n * a.out_stride + (size_t)oc * npix + p] = sum;
+}
+
+__global__ void escoin_stretch_kernel(const int *__restrict__ rowptr, int *__restrict__ colidx,
+                                      int M, int H, int W, int pad_h, int pad_w, int KH, int KW) {
+  // one wave per output channel, lanes stride the row (the reference uses one thread per
+  // row, math_functions.cu:708-719; same result)
+  const int oc = blockIdx.x * blockDim.y + threadIdx.y;
+  if (oc >= M) return;
+  for (int j = rowptr[oc] + threadIdx.x; j < rowptr[oc + 1]; j += 64) {
+    const int col = colidx[j];
+    const int kc = col % KW, kr = (col / KW) % KH, ic = col / (KW * KH);
+    colidx[j] = (ic * (H + pad_h) + kr) * (W + pad_w) + kc;
+  }
+}
+
+__global__ void escoin_copy_input_kernel(float *__restrict__ dst, const float *__restrict__ src,
+                                         int C, int H, int W, int pad_h, int pad_w) {
+  const long total = (long)C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long cy = i / W;
+    const int y = (int)(cy % H);
+    const long c = cy / H;
+    dst[(c * (H + pad_h) + y + pad_h) * (W + pad_w) + pad_w + x] = src[i];
+  }
+}
+
+__global__ void escoin_row_nnz_kernel(const float *__restrict__ A, int M, int N,
+                                      int *__restrict__ nnz_per_row) {
+  const int row = blockIdx.x;
+  if (row >= M) return;
+  int cnt = 0;
+  for (int j = threadIdx.x; j < N; j += 64) cnt += (A[(size_t)row * N + j] != 0.f) ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if (threadIdx.x == 0) nnz_per_row[row] = cnt;
+}
+
+// One wave per row; ballot-compaction keeps ascending column order.
+__global__ void escoin_row_fill_kernel(const float *__restrict__ A, int M, int N,
+                                       const int *__restrict__ rowptr, float *__restrict__ vals,
+                                       int *__restrict__ cols) {
+  const int row = blockIdx.x;
+  if (row >= M) return;
+  int base = rowptr[row];
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + threadIdx.x;
+    const float v = j < N ? A[(size_t)row * N + j] : 0.f;
+    const bool nz = v != 0.f;
+    const unsigned long long m = __ballot(nz);
+    const int before = __popcll(m & ((1ull << threadIdx.x) - 1ull));
+    if (nz) {
+      vals[base + before] = v;
+      cols[base + before] = j;
+    }
+    base += __popcll(m);
+  }
+}
+
+}  // namespace escoin
+
+using namespace escoin;
+
+extern "C" int escoin_gpu_sconv(int fuse_relu, int num, const float *input, int ifmap_size,
+                                const int *rowptr, const int *colidx, const float *values,
+                                const float *bias, int height, int width, int pad_h, int pad_w,
+                                int stride_h, int stride_w, int dilation_h, int dilation_w,
+                                int kernel_h, int kernel_w, float *output, int num_oc,
+                                int num_groups, void *stream) {
+  if (!input || !rowptr || !colidx || !values || !output || num < 1 || num_oc < 1 ||
+      num_groups < 1 || stride_h < 1 || stride_w < 1 || dilation_h < 1 || dilation_w < 1)
+    return fail(ESCOIN_EINVAL, "escoin_gpu_sconv: bad argument");
+  if (fuse_relu && !bias) return fail(ESCOIN_EINVAL, "escoin_gpu_sconv: FUSE_RELU needs bias");
+  PaddedArgs a;
+  a.in = input; a.out = output; a.rowptr = rowptr; a.colidx = colidx; a.vals = values;
+  a.bias = bias;
+  a.H = height; a.W = width; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.stride_h = stride_h; a.stride_w = stride_w; a.dil_h = dilation_h; a.dil_w = dilation_w;
+  a.OH = (height + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) / stride_h + 1;
+  a.OW = (width + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) / stride_w + 1;
+  a.num_oc = num_oc;
+  a.in_stride = (long)ifmap_size * num_groups;                 // math_functions.cu:566
+  a.out_stride = (long)num_oc * num_groups * a.OH * a.OW;      // :567
+  const int npix = a.OH * a.OW;
+  dim3 block(64, kWavesPerBlock, 1);
+  dim3 grid((npix + 63) / 64, (num_oc + kWavesPerBlock - 1) / kWavesPerBlock, num);
+  hipStream_t s = (hipStream_t)stream;
+  const bool dil = dilation_h != 1 || dilation_w != 1;
+  if (fuse_relu) {
+    if (dil) hipLaunchKernelGGL((escoin_sconv_padded_kernel<true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((escoin_sconv_padded_kernel<true, false>), grid, block, 0, s, a);
+  } else {
+    if (dil) hipLaunchKernelGGL((escoin_sconv_padded_kernel<false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((escoin_sconv_padded_kernel<false, false>), grid, block, 0, s, a);
+  }
+  ESCOIN_HIP_TRY(hipGetLastError());
+  return ESCOIN_OK;
+}
+
+extern "C" int escoin_gpu_stretch(const int *rowptr, int *colidx, int M, int height, int width,
+                                  int pad_h, int pad_w, int kernel_h, int kernel_w,
+                                  void *stream) {
+  if (!rowptr || !colidx || M < 1) return fail(ESCOIN_EINVAL, "escoin_gpu_stretch: bad argument");
+  dim3 block(64, 4, 1);
+  dim3 grid((M + 3) / 4, 1, 1);
+  hipLaunchKernelGGL(escoin_stretch_kernel, grid, block, 0, (hipStream_t)stream, rowptr, colidx,
+                     M, height, width, pad_h, pad_w, kernel_h, kernel_w);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  return ESCOIN_OK;
+}
+
+extern "C" int escoin_copy_input_data(float *dst, const float *src, int num_channels, int height,
+                                      int width, int pad_h, int pad_w, void *stream) {
+  if (!dst || !src || num_channels < 1 || height < 1 || width < 1)
+    return fail(ESCOIN_EINVAL, "escoin_copy_input_data: bad argument");
+  const long total = (long)num_channels * height * width;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(escoin_copy_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     dst, src, num_channels, height, width, pad_h, pad_w);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  return ESCOIN_OK;
+}
+
+extern "C" int escoin_gpu_sparse_dense2csr(int M, int N, const float *A, int *nnz_per_row,
+                                           float *A_nonzero_buf, int *A_idx_pointer_buf,
+                                           int *A_nonzero_idx_buf, int *nnz_total,
+                                           void *stream) {
+  if (M < 1 || N < 1 || !A || !nnz_per_row || !A_nonzero_buf || !A_idx_pointer_buf ||
+      !A_nonzero_idx_buf || !nnz_total)
+    return fail(ESCOIN_EINVAL, "escoin_gpu_sparse_dense2csr: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(escoin_row_nnz_kernel, dim3(M), dim3(64), 0, s, A, M, N, nnz_per_row);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  std::vector<int> cnt(M), ptr(M + 1);
+  ESCOIN_HIP_TRY(hipMemcpyAsync(cnt.data(), nnz_per_row, sizeof(int) * M, hipMemcpyDeviceToHost, s));
+  ESCOIN_HIP_TRY(hipStreamSynchronize(s));
+  ptr[0] = 0;
+  for (int i = 0; i < M; ++i) ptr[i + 1] = ptr[i] + cnt[i];
+  ESCOIN_HIP_TRY(hipMemcpyAsync(A_idx_pointer_buf, ptr.data(), sizeof(int) * (M + 1),
+                                hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(escoin_row_fill_kernel, dim3(M), dim3(64), 0, s, A, M, N,
+                     (const int *)A_idx_pointer_buf, A_nonzero_buf, A_nonzero_idx_buf);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  ESCOIN_HIP_TRY(hipStreamSynchronize(s));  // ptr (host) must outlive the async copy
+  *nnz_total = ptr[M];
+  return ESCOIN_OK;
+}

@@ -1,0 +1,179 @@
+/*
+ * include/escoin.h -- C ABI of libescoin_hip.so
+ *
+ * MI355X (gfx950) direct sparse convolution forward: the drop-in for the path
+ *   ConvolutionLayer<Dtype>::Forward_gpu            src/caffe/layers/conv_layer.cu:8-40
+ *     -> BaseConvolutionLayer::forward_gpu_sconv[_par]   base_conv_layer.cpp:748-848
+ *        -> caffe_gpu_sconv + forward_gpu_bias           math_functions.cu:590-704,
+ *                                                        base_conv_layer.cpp:850-856
+ *   fed by BaseConvolutionLayer::WeightAlign             base_conv_layer.cpp:46-273
+ * of chenxuhao/caffe-escoin (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no torch / STL types cross this boundary;
+ *   - every entry point returns 0 on success and a negative ESCOIN_E* code on
+ *     failure; escoin_last_error() returns the message of the calling thread's last
+ *     failure.  The reference aborts on every error (glog CHECK / CUDA_CHECK,
+ *     include/caffe/util/device_alternate.hpp:51-78); the C++ Layer shim
+ *     (caffe-escoin_amd/caffe_shim/) turns a non-zero return into that abort;
+ *   - all tensors fp32 NCHW contiguous, all indices int32, as in the reference;
+ *   - device pointers are HIP device pointers on the current device; `stream` is a
+ *     hipStream_t passed as void* (NULL = the default stream, which is what every
+ *     reference kernel launch uses);
+ *   - the caller owns bottom / top / bias / dense-weight memory; a plan owns its CSR
+ *     arrays, the blocked weight streams and its scratch, and frees them in
+ *     escoin_plan_destroy (reference: layer dtor, base_conv_layer.cpp:16-42);
+ *   - thread-compatible: one plan per (host thread, device), like a Caffe layer
+ *     instance (common.cpp:13-19 keeps the Caffe singleton thread-local).
+ *   - there is NO CPU fallback in this library: without a HIP device every compute
+ *     entry point fails with ESCOIN_ENODEVICE.
+ */
+#ifndef ESCOIN_H_
+#define ESCOIN_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Symbol visibility: the library is built with -fvisibility=hidden. */
+#if defined(ESCOIN_BUILD) && defined(__GNUC__)
+#define ESCOIN_API __attribute__((visibility("default")))
+#else
+#define ESCOIN_API
+#endif
+
+#define ESCOIN_OK 0
+#define ESCOIN_EINVAL (-1)    /* bad argument / unsupported geometry            */
+#define ESCOIN_ENOMEM (-2)    /* host or device allocation failed               */
+#define ESCOIN_EHIP (-3)      /* a HIP runtime call or kernel launch failed     */
+#define ESCOIN_ESTATE (-4)    /* forward before weight_align / set_csr          */
+#define ESCOIN_ENODEVICE (-5) /* no HIP device visible                          */
+
+/* Caffe::ConvMode, include/caffe/common.hpp:112.  Only the two direct-sparse modes are
+ * served by this library; they differ in the reference only by launch granularity
+ * (per image vs whole batch, conv_layer.cu:16-26) and produce the same numbers. */
+#define ESCOIN_CONV_MODE_LOWERED_GEMM 0
+#define ESCOIN_CONV_MODE_LOWERED_SPARSE 1
+#define ESCOIN_CONV_MODE_SCONV 2
+#define ESCOIN_CONV_MODE_SCONV_PAR 3
+
+/* Which kernel family a plan uses (escoin_plan_set_option("kernel", ...)). */
+#define ESCOIN_KERNEL_AUTO 0
+#define ESCOIN_KERNEL_GENERIC 1 /* one lane = one output pixel, CSR order kept    */
+#define ESCOIN_KERNEL_TILED 2   /* LDS-staged tiles, row-grouped weight stream    */
+
+/* Geometry of one ConvolutionLayer: what LayerSetUp/Reshape derive from
+ * ConvolutionParameter + the bottom shape (base_conv_layer.cpp:276-530). */
+typedef struct escoin_conv_desc {
+  int N;        /* num_: largest batch a forward call may carry                 */
+  int C, H, W;  /* channels_ (all groups), conv_input_shape_[1..2]              */
+  int M;        /* num_output_ (all groups)                                     */
+  int KH, KW;   /* kernel_shape_                                                */
+  int pad_h, pad_w;
+  int stride_h, stride_w;
+  int dil_h, dil_w;
+  int group;    /* group_                                                       */
+  int has_bias; /* bias_term_: forward adds bias[oc] once (conv_layer.cu:21-24) */
+  int fuse_relu;/* ConvolutionReLU: max(x + bias, 0) (conv_relu_layer.cu:8-30)  */
+} escoin_conv_desc;
+
+typedef struct escoin_plan escoin_plan;
+
+/* Message of this thread's last failed call ("" if none). */
+ESCOIN_API const char *escoin_last_error(void);
+
+/* Number of visible HIP devices (0 without a GPU; never fails). */
+ESCOIN_API int escoin_device_count(void);
+
+/* ConvolutionLayer::compute_output_shape, conv_layer.cpp:8-22. */
+ESCOIN_API int escoin_out_shape(const escoin_conv_desc *desc, int *out_h, int *out_w);
+
+/* Length in floats of the reference's shared-halo padded image
+ * C(H+ph)(W+pw) + ph(W+2pw), base_conv_layer.cpp:71,596. */
+ESCOIN_API long escoin_padded_len(const escoin_conv_desc *desc);
+
+/* LayerSetUp + Reshape: validates the geometry and creates an empty plan.
+ * No device work happens here, so it also succeeds on a machine without a GPU. */
+ESCOIN_API int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan);
+ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
+
+/* Options: "kernel" = ESCOIN_KERNEL_*, "conv_mode" = ESCOIN_CONV_MODE_*,
+ * "dense_gate" = 0/1 (1: mimic the reference's per-layer gate that sends
+ * density(group 0) > 0.2 to the dense path, base_conv_layer.cpp:750-755; the dense
+ * path here is the same kernels run on the unpruned CSR). Must precede weight_align. */
+ESCOIN_API int escoin_plan_set_option(escoin_plan *plan, const char *key, int value);
+
+/* WeightAlign(): dense blobs_[0] (M x C/g x KH x KW, zeros = pruned) -> per-group CSR
+ * (caffe_{cpu,gpu}_sparse_dense2csr, math_functions.cpp:77-107 / .cu:103-152), index
+ * stretch (base_conv_layer.cpp:96-107 / stretch_kernel math_functions.cu:706-727) and
+ * the MI355X-specific blocked weight streams; uploads everything to the device.
+ * `dense_w` is a host pointer, or a device pointer when w_on_device != 0. One-time. */
+ESCOIN_API int escoin_weight_align(escoin_plan *plan, const float *dense_w, int w_on_device,
+                        void *stream);
+
+/* CSR hand-off without the dense blob (what a broadcast receiver calls, the
+ * counterpart of NCCL<Dtype>::Broadcast, parallel.cpp:189-200).  Host arrays:
+ * rowptr[group*(M/group+1)] group-local and 0-based, colidx/values concatenated over
+ * groups, colidx UNSTRETCHED (ic*KH*KW + kr*KW + kc), nnz_per_group[group]. */
+ESCOIN_API int escoin_plan_set_csr(escoin_plan *plan, const int *rowptr, const int *colidx,
+                        const float *values, const int *nnz_per_group, void *stream);
+
+/* nnz of one group (nz_num_[g], base_conv_layer.cpp:247), or of all groups for
+ * group < 0.  Negative on error. */
+ESCOIN_API long escoin_plan_nnz(const escoin_plan *plan, int group);
+
+/* Copies the plan's CSR to host arrays sized as in escoin_plan_set_csr.  With
+ * stretched != 0 colidx is the reference's stretched index
+ * (ic*(H+ph)+kr)*(W+pw)+kc, i.e. exactly nz_weight_indices_ after WeightAlign. */
+ESCOIN_API int escoin_plan_get_csr(const escoin_plan *plan, int *rowptr, int *colidx, float *values,
+                        int stretched);
+
+/* Device bytes owned by the plan (CSR + weight streams + scratch). */
+ESCOIN_API size_t escoin_plan_workspace_bytes(const escoin_plan *plan);
+
+/* Name of the device kernel the plan launches (the symbol rocprofv3 reports). */
+ESCOIN_API const char *escoin_plan_kernel_name(const escoin_plan *plan);
+
+/* Forward_gpu body for one bottom/top pair, whole batch, asynchronous on `stream`:
+ *   top[n][oc] = sconv(bottom[n], CSR)[oc] (+ bias[oc]) (then ReLU if fuse_relu)
+ * bottom: n_images x C x H x W, top: n_images x M x OH x OW, bias: M floats or NULL.
+ * bias may be NULL even when has_bias was set (the reference dereferences blobs_[1]
+ * unconditionally, base_conv_layer.cpp:648 -- not copied).  n_images <= desc.N. */
+ESCOIN_API int escoin_forward(escoin_plan *plan, const float *bottom_dev, const float *bias_dev,
+                   float *top_dev, int n_images, void *stream);
+
+/* ---- math_functions-level entry points (drop-ins for the reference's GPU helpers,
+ * include/caffe/util/math_functions.hpp:194-230).  They operate on the reference's own
+ * data layout (shared-halo padded input, stretched CSR) so a Caffe-HIP tree can call
+ * them from an unmodified base_conv_layer.cpp. ------------------------------------ */
+
+/* caffe_gpu_sconv<float>, math_functions.cu:590-704 (bias applied iff FUSE_RELU, as
+ * there: :215,421 vs :282).  `input` is the padded image(s), per-image stride
+ * ifmap_size*num_groups floats (math_functions.cu:566). */
+ESCOIN_API int escoin_gpu_sconv(int fuse_relu, int num, const float *input, int ifmap_size,
+                     const int *rowptr, const int *colidx, const float *values,
+                     const float *bias, int height, int width, int pad_h, int pad_w,
+                     int stride_h, int stride_w, int dilation_h, int dilation_w,
+                     int kernel_h, int kernel_w, float *output, int num_oc, int num_groups,
+                     void *stream);
+
+/* caffe_gpu_stretch, math_functions.cu:706-727 (in place on device colidx). */
+ESCOIN_API int escoin_gpu_stretch(const int *rowptr, int *colidx, int M, int height, int width,
+                       int pad_h, int pad_w, int kernel_h, int kernel_w, void *stream);
+
+/* copy_input_data<float>, math_functions.cu:729-766: dense image -> padded layout. */
+ESCOIN_API int escoin_copy_input_data(float *dst, const float *src, int num_channels, int height,
+                           int width, int pad_h, int pad_w, void *stream);
+
+/* caffe_gpu_sparse_dense2csr<float>, math_functions.cu:103-152: device dense M x N ->
+ * device CSR (0-based, ascending columns); *nnz_total written on the host. */
+ESCOIN_API int escoin_gpu_sparse_dense2csr(int M, int N, const float *A, int *nnz_per_row,
+                                float *A_nonzero_buf, int *A_idx_pointer_buf,
+                                int *A_nonzero_idx_buf, int *nnz_total, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESCOIN_H_ */

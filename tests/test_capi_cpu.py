@@ -1,0 +1,113 @@
+"""C-ABI host logic without a GPU: the library loads, exports every symbol include/escoin.h
+declares, validates geometry like LayerSetUp/Reshape, and FAILS LOUDLY (no CPU fallback)
+when a compute entry point is reached on a machine without a HIP device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def _no_gpu(pkg):
+    return pkg.device_count() == 0
+
+
+def test_header_symbols_are_all_exported(pkg):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "escoin.h")).read()
+    declared = sorted(set(re.findall(r"ESCOIN_API[^;(]*?(escoin_\w+)\s*\(", hdr)))
+    assert declared, "no declarations parsed from include/escoin.h"
+    assert sorted(pkg.API_SYMBOLS) == declared
+    lib = C.CDLL(pkg.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libescoin_hip.so does not export %s" % name
+
+
+def test_out_shape_matches_reference_formula(pkg, oracle):
+    # conv_layer.cpp:8-22 on the reference's test shapes and the config layers
+    for (h, k, p, s, d) in [(6, 3, 0, 2, 1), (8, 3, 0, 1, 2), (56, 3, 1, 1, 1), (27, 5, 2, 1, 1),
+                            (12, 5, 0, 1, 1), (227, 11, 0, 4, 1), (7, 3, 1, 1, 1)]:
+        desc = pkg.ConvDesc(1, 1, h, h, 1, k, k, p, p, s, s, d, d, 1, 0, 0)
+        want = (h + 2 * p - (d * (k - 1) + 1)) // s + 1
+        assert pkg.out_shape(desc) == (want, want)
+        assert oracle.out_hw(oracle.geom(1, h, h, 1, k, k, p, p, s, s, d, d)) == (want, want)
+
+
+def test_padded_len(pkg):
+    d = pkg.ConvDesc(1, 64, 56, 56, 64, 3, 3, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+    assert pkg.lib().escoin_padded_len(C.byref(d)) == 207994
+    d = pkg.ConvDesc(1, 96, 27, 27, 256, 5, 5, 2, 2, 1, 1, 1, 1, 2, 1, 0)
+    assert pkg.lib().escoin_padded_len(C.byref(d)) == 80798       # AlexNet conv2
+
+
+@pytest.mark.parametrize("bad", [
+    dict(C=0), dict(M=0), dict(group=3), dict(stride_h=0), dict(dil_w=0), dict(pad_h=-1),
+    dict(KH=9, H=4, pad_h=0),          # empty output
+    dict(N=0),
+])
+def test_plan_create_rejects_bad_geometry(pkg, bad):
+    base = dict(N=2, C=4, H=8, W=8, M=4, KH=3, KW=3, pad_h=1, pad_w=1, stride_h=1, stride_w=1,
+                dil_h=1, dil_w=1, group=1, has_bias=1, fuse_relu=0)
+    base.update(bad)
+    desc = pkg.ConvDesc(**base)
+    h = C.c_void_p()
+    rc = pkg.lib().escoin_plan_create(C.byref(desc), C.byref(h))
+    assert rc == -1 and not h.value
+    assert pkg.lib().escoin_last_error()      # a message is recorded
+
+
+def test_plan_lifecycle_and_options_on_host(pkg):
+    desc = pkg.ConvDesc(4, 6, 8, 8, 6, 3, 3, 1, 1, 1, 1, 1, 1, 3, 1, 0)
+    plan = pkg.Plan(desc)
+    assert plan.out_hw == (8, 8)
+    assert plan.nnz() == 0 and plan.workspace_bytes == 0
+    plan.set_option("kernel", pkg.KERNEL_GENERIC)
+    plan.set_option("conv_mode", pkg.CONV_MODE_SCONV)
+    with pytest.raises(pkg.EscoinError):
+        plan.set_option("conv_mode", 0)              # LOWERED_GEMM is not this library's path
+    with pytest.raises(pkg.EscoinError):
+        plan.set_option("no_such_option", 1)
+    with pytest.raises(pkg.EscoinError):
+        plan.nnz(group=7)
+    plan.close()
+    plan.close()                                     # idempotent
+
+
+def test_forward_before_align_is_a_state_error(pkg):
+    desc = pkg.ConvDesc(1, 2, 4, 4, 2, 3, 3, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+    plan = pkg.Plan(desc)
+    rc = pkg.lib().escoin_forward(plan._h, C.c_void_p(16), None, C.c_void_p(16), 1, None)
+    assert rc == -4
+    rc = pkg.lib().escoin_forward(plan._h, None, None, C.c_void_p(16), 1, None)
+    assert rc == -1
+
+
+def test_no_cpu_fallback_fails_loudly_without_device(pkg, synth):
+    if not _no_gpu(pkg):
+        pytest.skip("a HIP device is visible")
+    s = synth.lenet_conv2(N=1)[0]
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    with pytest.raises(pkg.EscoinError) as e:
+        plan.weight_align(synth.pruned_weights(s, 1))
+    assert "no HIP device" in str(e.value)
+    # math_functions-level entry points validate their arguments on the host
+    assert pkg.lib().escoin_gpu_stretch(None, None, 0, 1, 1, 0, 0, 1, 1, None) == -1
+
+
+def test_set_csr_validates_on_host(pkg):
+    desc = pkg.ConvDesc(1, 2, 4, 4, 2, 3, 3, 1, 1, 1, 1, 1, 1, 1, 0, 0)
+    plan = pkg.Plan(desc)
+    rp = np.array([0, 2, 1], np.int32)               # not monotone / does not match nnz
+    ci = np.array([0, 5], np.int32)
+    va = np.array([1, 2], np.float32)
+    with pytest.raises(pkg.EscoinError):
+        plan.set_csr(rp, ci, va, [2])
+    with pytest.raises(pkg.EscoinError):
+        plan.set_csr(np.array([0, 1, 2], np.int32), np.array([0, 99], np.int32), va, [2])
+
+
+def test_package_is_importable_under_alias():
+    import __graft_entry__ as ge
+    p = ge.load_package()
+    assert p.__name__ == "caffe_escoin_amd" and hasattr(p, "synth") and hasattr(p, "Plan")

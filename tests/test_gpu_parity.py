@@ -1,0 +1,267 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle -- needs an MI355X.
+
+Tolerance (BASELINE.json north_star): 1e-4 relative fp32, defined as
+    max|got - want| / max(1e-6, max|want|) <= 1e-4        
+The generic kernel keeps the reference's summation order and must be BIT-EXACT.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import Golden, golden_params, naive_conv, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    assert pkg.device_count() >= 1
+    return torch
+
+
+def _run(pkg, torch, desc, w, x, bias, kernel):
+    plan = pkg.Plan(desc, kernel=kernel)
+    plan.weight_align(w)
+    dev = torch.device("cuda:0")
+    top = plan.forward(torch.from_numpy(np.ascontiguousarray(x)).to(dev),
+                       torch.from_numpy(bias).to(dev) if bias is not None else None)
+    torch.cuda.synchronize()
+    name = plan.kernel_name
+    out = top.cpu().numpy()
+    plan.close()
+    return out, name
+
+
+def _kernels(pkg):
+    return [pkg.KERNEL_GENERIC, pkg.KERNEL_AUTO]
+
+
+@pytest.mark.parametrize("path", golden_params())
+def test_golden_fixtures(pkg, torch_cuda, path):
+    gd = Golden(path)
+    for kernel in _kernels(pkg):
+        got, name = _run(pkg, torch_cuda, gd.desc(pkg), gd.w, gd.x, gd.bias, kernel)
+        assert got.shape == gd.top.shape
+        if "generic" in name:
+            assert np.array_equal(got, gd.top), "%s: generic kernel must be bit-exact" % gd.name
+        assert rel_err(got, gd.top) <= TOL, "%s via %s" % (gd.name, name)
+
+
+def _config_shapes(synth):
+    return (synth.lenet_conv2(N=3) + synth.alexnet(N=3) + synth.resnet50_3x3(N=3) +
+            [synth.googlenet_1x1(N=3)[i] for i in (0, 1, 30, 36, 38)])
+
+
+def test_config_layers_small_batch_vs_oracle(pkg, oracle, synth, torch_cuda):
+    """Every layer shape of BASELINE.json's configs at its real channel counts, batch 3."""
+    for k, s in enumerate(_config_shapes(synth)):
+        w = synth.pruned_weights(s, 100 + k)
+        b = synth.bias_vector(s, 200 + k)
+        x = synth.activations(s, 300 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                        s.dil_h, s.dil_w, s.group)
+        want = oracle.conv_forward(g, x, w, b, gate=False, threads=4)
+        for kernel in _kernels(pkg):
+            got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel)
+            if "generic" in name:
+                assert np.array_equal(got, want), s.name
+            assert rel_err(got, want) <= TOL, "%s via %s: %g" % (s.name, name, rel_err(got, want))
+
+
+def test_sparsity_sweep_60_to_95(pkg, oracle, synth, torch_cuda):
+    for sp in (0.6, 0.7, 0.8, 0.9, 0.95, 1.0, 0.0):
+        s = synth.shape("sweep", 2, 32, 14, 14, 48, 3, pad=1, sparsity=sp)
+        w, b, x = synth.pruned_weights(s, 1), synth.bias_vector(s, 2), synth.activations(s, 3)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w)
+        want = oracle.conv_forward(g, x, w, b, gate=False)
+        for kernel in _kernels(pkg):
+            got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel)
+            assert rel_err(got, want) <= TOL, "sparsity %g via %s" % (sp, name)
+
+
+def test_odd_geometries(pkg, oracle, synth, torch_cuda):
+    S = synth.shape
+    cases = [
+        S("s2", 2, 8, 15, 13, 8, 3, pad=1, stride=2, sparsity=0.7),
+        S("d2", 2, 8, 15, 13, 8, 3, pad=2, dil=2, sparsity=0.7),
+        S("k1s2", 2, 8, 9, 9, 8, 1, stride=2, sparsity=0.5),
+        S("k7p3", 1, 3, 20, 20, 8, 7, pad=3, sparsity=0.5),
+        S("k3p0", 2, 8, 10, 10, 8, 3, sparsity=0.8),
+        S("k3p2", 2, 4, 6, 6, 4, 3, pad=2, sparsity=0.5),
+        S("g4", 2, 16, 9, 9, 12, 3, pad=1, group=4, sparsity=0.75),
+        S("w1", 2, 8, 5, 1, 8, 3, KW=1, pad=1, pad_w=0, sparsity=0.5),
+        S("h1", 2, 8, 1, 9, 8, 1, KW=3, pad=0, pad_w=1, sparsity=0.5),
+        S("wide", 1, 4, 3, 300, 4, 3, pad=1, sparsity=0.6),
+        S("n1c1m1", 1, 1, 4, 4, 1, 3, pad=1, sparsity=0.0),
+        S("w5", 3, 16, 5, 5, 16, 3, pad=1, sparsity=0.8),
+        S("w20k5", 2, 8, 20, 20, 8, 5, pad=2, sparsity=0.8),
+        S("w33", 2, 8, 33, 33, 8, 3, pad=1, sparsity=0.8),
+    ]
+    for k, s in enumerate(cases):
+        w, b, x = synth.pruned_weights(s, k), synth.bias_vector(s, k + 50), synth.activations(s, k + 90)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                        s.dil_h, s.dil_w, s.group)
+        want = oracle.conv_forward(g, x, w, b, gate=False)
+        assert rel_err(want, naive_conv(x, w, b, s)) <= 1e-5
+        for kernel in _kernels(pkg):
+            got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel)
+            assert rel_err(got, want) <= TOL, "%s via %s: %g" % (s.name, name, rel_err(got, want))
+
+
+def test_bias_null_relu_and_partial_batch(pkg, oracle, synth, torch_cuda):
+    torch = torch_cuda
+    s = synth.shape("b", 5, 16, 14, 14, 24, 3, pad=1, sparsity=0.85)
+    w, b, x = synth.pruned_weights(s, 1), synth.bias_vector(s, 2), synth.activations(s, 3)
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w)
+    dev = torch.device("cuda:0")
+    for kernel in _kernels(pkg):
+        # has_bias set but bias pointer NULL is legal (reference quirk 2 is not copied)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel)
+        plan.weight_align(w)
+        xd = torch.from_numpy(x).to(dev)
+        nb = plan.forward(xd, None).cpu().numpy()
+        assert rel_err(nb, oracle.conv_forward(g, x, w, None, gate=False)) <= TOL
+        # n_images < desc.N: only the first images are touched
+        top = torch.full((5, s.M, 14, 14), 7.0, device=dev)
+        plan.forward_ptr(xd.data_ptr(), 0, top.data_ptr(), 2,
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        t = top.cpu().numpy()
+        assert rel_err(t[:2], nb[:2]) <= 1e-6 and (t[2:] == 7.0).all()
+        with pytest.raises(pkg.EscoinError):
+            plan.forward_ptr(xd.data_ptr(), 0, top.data_ptr(), 6, None)   # > desc.N
+        plan.close()
+        # fused bias + ReLU (ConvolutionReLU)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=True), kernel=kernel)
+        plan.weight_align(w)
+        r = plan.forward(xd, torch.from_numpy(b).to(dev)).cpu().numpy()
+        assert rel_err(r, oracle.conv_forward(g, x, w, b, relu=True, gate=False)) <= TOL
+        assert (r >= 0).all()
+        plan.close()
+
+
+def test_weight_align_from_device_and_csr_roundtrip(pkg, oracle, synth, torch_cuda):
+    torch = torch_cuda
+    s = synth.alexnet(N=2)[0]                       # group = 2
+    w, b, x = synth.pruned_weights(s, 1), synth.bias_vector(s, 2), synth.activations(s, 3)
+    dev = torch.device("cuda:0")
+    p1 = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    p1.weight_align(torch.from_numpy(w).to(dev))    # device blob, like blobs_[0]->gpu_data()
+    rp, ci, va, ng = p1.get_csr()
+    assert ng.tolist() == [synth.nnz_of(s) // 2] * 2 and p1.nnz() == synth.nnz_of(s)
+    # CSR equals the reference's dense2csr + stretch (WeightAlign) bit for bit
+    mg, cg = s.M // s.group, s.C // s.group
+    _, ci_s, _, _ = p1.get_csr(stretched=True)
+    off = 0
+    for grp in range(s.group):
+        orp, oci, ova = oracle.dense2csr(w[grp * mg:(grp + 1) * mg].reshape(mg, cg * s.KH * s.KW))
+        n = len(oci)
+        assert np.array_equal(rp[grp * (mg + 1):(grp + 1) * (mg + 1)], orp)
+        assert np.array_equal(ci[off:off + n], oci) and np.array_equal(va[off:off + n], ova)
+        assert np.array_equal(ci_s[off:off + n],
+                              oracle.stretch(orp, oci, s.KH, s.KW, s.H, s.W, s.pad_h, s.pad_w))
+        off += n
+    # a second plan fed only the CSR (what a broadcast receiver does) gives identical output
+    p2 = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    p2.set_csr(rp, ci, va, ng)
+    xd, bd = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
+    a = p1.forward(xd, bd).cpu().numpy()
+    c = p2.forward(xd, bd).cpu().numpy()
+    assert np.array_equal(a, c)
+    assert p1.workspace_bytes > 0
+    p1.close()
+    p2.close()
+
+
+def test_math_functions_level_dropins(pkg, oracle, synth, torch_cuda):
+    """escoin_gpu_sparse_dense2csr / gpu_stretch / copy_input_data / gpu_sconv on the
+    reference's own layouts (padded input, stretched CSR), as base_conv_layer.cpp calls them."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    L = pkg.lib()
+    for s in (synth.shape("m", 3, 6, 9, 8, 5, 3, pad=1, sparsity=0.6),
+              synth.shape("md", 2, 4, 9, 8, 5, 3, pad=2, dil=2, sparsity=0.5),
+              synth.shape("ms", 2, 4, 9, 8, 5, 3, pad=1, stride=2, sparsity=0.5)):
+        w, x = synth.pruned_weights(s, 1), synth.activations(s, 2)
+        bias = synth.uniform(3, s.M, -0.1, 0.1)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                        s.dil_h, s.dil_w)
+        kdim = s.C * s.KH * s.KW
+        A = torch.from_numpy(w.reshape(s.M, kdim)).to(dev)
+        vals = torch.zeros(s.M * kdim, device=dev)
+        cols = torch.zeros(s.M * kdim, dtype=torch.int32, device=dev)
+        rowp = torch.zeros(s.M + 1, dtype=torch.int32, device=dev)
+        perrow = torch.zeros(s.M, dtype=torch.int32, device=dev)
+        nnz = C.c_int()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        assert L.escoin_gpu_sparse_dense2csr(s.M, kdim, P(A), P(perrow), P(vals), P(rowp), P(cols),
+                                             C.byref(nnz), None) == 0
+        orp, oci, ova = oracle.dense2csr(w.reshape(s.M, kdim))
+        assert nnz.value == len(oci)
+        assert np.array_equal(rowp.cpu().numpy(), orp)
+        assert np.array_equal(cols.cpu().numpy()[:nnz.value], oci)
+        assert np.array_equal(vals.cpu().numpy()[:nnz.value], ova)
+        assert np.array_equal(perrow.cpu().numpy(), np.diff(orp))
+        assert L.escoin_gpu_stretch(P(rowp), P(cols), s.M, s.H, s.W, s.pad_h, s.pad_w, s.KH, s.KW,
+                                    None) == 0
+        ocs = oracle.stretch(orp, oci, s.KH, s.KW, s.H, s.W, s.pad_h, s.pad_w)
+        assert np.array_equal(cols.cpu().numpy()[:nnz.value], ocs)
+        plen = oracle.padded_len(g)
+        N = x.shape[0]
+        ifmap = s.C * (s.H + s.pad_h) * (s.W + s.pad_w)
+        padded = torch.zeros(N * ifmap + plen, device=dev)       # SCONV_PAR stride, quirk 9
+        xd = torch.from_numpy(x).to(dev)
+        for n in range(N):
+            assert L.escoin_copy_input_data(C.c_void_p(padded.data_ptr() + 4 * n * ifmap),
+                                            C.c_void_p(xd.data_ptr() + 4 * n * s.C * s.H * s.W),
+                                            s.C, s.H, s.W, s.pad_h, s.pad_w, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(padded.cpu().numpy()[:plen], oracle.pad_input(g, x[0]))
+        oh, ow = oracle.out_hw(g)
+        out = torch.zeros(N, s.M, oh, ow, device=dev)
+        bd = torch.from_numpy(bias).to(dev)
+        for relu in (0, 1):
+            assert L.escoin_gpu_sconv(relu, N, P(padded), ifmap, P(rowp), P(cols), P(vals), P(bd),
+                                      s.H, s.W, s.pad_h, s.pad_w, s.stride_h, s.stride_w, s.dil_h,
+                                      s.dil_w, s.KH, s.KW, P(out), s.M, 1, None) == 0
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            base = oracle.conv_forward(g, x, w, None, gate=False)
+            if relu:
+                want = np.maximum(base + bias[None, :, None, None], 0)
+                assert rel_err(got, want) <= 1e-6
+            else:
+                assert np.array_equal(got, base)      # non-ReLU kernels ignore bias (quirk 10)
+
+
+def test_linearity_and_batch_independence_full_size(pkg, synth, torch_cuda):
+    """Size-independent properties at BASELINE's full batch (res3 N=256): conv(a*x + y) ==
+    a*conv(x) + conv(y) and image n's output does not depend on its batch neighbours."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    s = synth.resnet50_3x3(N=256)[1]
+    w = synth.pruned_weights(s, 1)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    plan.weight_align(w)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    x = torch.rand((s.N, s.C, s.H, s.W), device=dev, generator=gen) * 2 - 1
+    y = torch.rand((s.N, s.C, s.H, s.W), device=dev, generator=gen) * 2 - 1
+    fx, fy = plan.forward(x), plan.forward(y)
+    fz = plan.forward(2.0 * x + y)
+    scale = float(fz.abs().max())
+    assert float((fz - (2.0 * fx + fy)).abs().max()) / scale <= TOL
+    # batch independence: a shuffled batch gives the shuffled outputs, bit for bit
+    perm = torch.randperm(s.N, device=dev, generator=gen)
+    assert torch.equal(plan.forward(x[perm].contiguous()), fx[perm])
+    # and a generic-kernel plan agrees on a slice at full channel count
+    ref = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_GENERIC)
+    ref.weight_align(w)
+    fr = ref.forward(x[:8].contiguous())
+    assert float((fr - fx[:8]).abs().max()) / scale <= TOL
+    plan.close()
+    ref.close()
