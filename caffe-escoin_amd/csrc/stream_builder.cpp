@@ -1,0 +1,149 @@
+// stream_builder.cpp -- see stream_builder.h
+#include "stream_builder.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace escoin {
+
+static int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) {
+  Tiling t;
+  // epilogue shifts: s = kc - pad_w must satisfy |s| <= 4 (one neighbouring quad)
+  if (g.KW < 1 || g.KW > 5 || g.pad_w > 4 || g.KW - 1 - g.pad_w > 4) return t;
+  if (g.W > 256 || g.OH < 1 || g.OW < 1) return t;
+  if (waves_per_wg != 4 && waves_per_wg != 8) return t;
+  t.KW = g.KW;
+  t.KH = g.KH;
+  t.S4 = next_pow2((g.W + 3) / 4);
+  t.RS = 4 * t.S4;
+  t.rows_per_wave = 64 / t.S4;
+  t.G = std::min(32, kMaxAccRegs / (4 * g.KW));   // KW=1:32  KW=3:16  KW=5:9
+  if (g.KW == 5) t.G = 8;
+  t.G = std::min(t.G, std::max(1, g.Mg));
+  t.n_ocg = (g.Mg + t.G - 1) / t.G;
+  t.waves = waves_per_wg;
+  t.oc_waves = 1;
+  while (t.oc_waves * 2 <= waves_per_wg && t.oc_waves < t.n_ocg) t.oc_waves *= 2;
+  t.pix_waves = waves_per_wg / t.oc_waves;
+  t.n_ocblk = (t.n_ocg + t.oc_waves - 1) / t.oc_waves;
+  const int rows_per_wg = t.pix_waves * t.rows_per_wave;
+  if (g.OH <= rows_per_wg) {
+    t.band_mode = false;
+    t.tr = g.OH;
+    t.nseg = rows_per_wg / g.OH;
+    t.bands = 1;
+  } else {
+    t.band_mode = true;
+    t.tr = rows_per_wg;
+    t.nseg = 1;
+    t.bands = (g.OH + t.tr - 1) / t.tr;
+  }
+  t.plane_rows = t.tr + g.KH - 1;
+  t.plane_seg_floats = t.plane_rows * t.RS;
+  t.plane_ch_floats = t.nseg * t.plane_seg_floats;
+  const int per_ch = t.plane_ch_floats * 4;
+  int icb = lds_budget_bytes / per_ch;
+  if (icb < 1) return t;                       // one channel does not fit
+  icb = std::min(icb, g.Cg);
+  // balance the blocks: same number of blocks, evenly sized
+  t.n_icb = (g.Cg + icb - 1) / icb;
+  t.icb = (g.Cg + t.n_icb - 1) / t.n_icb;
+  t.lds_bytes = t.icb * per_ch;
+  t.ok = true;
+  return t;
+}
+
+namespace {
+struct Rec {
+  float val;
+  uint32_t m0;
+};
+struct Group {
+  uint32_t lds_off;
+  std::vector<Rec> recs;
+};
+}  // namespace
+
+WeightStream build_stream(const ConvGeom &g, const Tiling &t,
+                          const std::vector<std::vector<int>> &rowptr,
+                          const std::vector<std::vector<int>> &colidx,
+                          const std::vector<std::vector<float>> &values) {
+  WeightStream ws;
+  ws.unit_off.assign((size_t)g.group * t.n_ocg * t.n_icb, 0);
+  const int rows_per_blk = t.icb * g.KH;
+  std::vector<std::vector<Rec>> rows(rows_per_blk);   // records per (ic_local, kr)
+  for (int cg = 0; cg < g.group; ++cg) {
+    for (int ocg = 0; ocg < t.n_ocg; ++ocg) {
+      for (int blk = 0; blk < t.n_icb; ++blk) {
+        for (auto &r : rows) r.clear();
+        const int ic_lo = blk * t.icb, ic_hi = std::min(g.Cg, ic_lo + t.icb);
+        for (int gl = 0; gl < t.G; ++gl) {
+          const int m = ocg * t.G + gl;
+          if (m >= g.Mg) break;
+          for (int j = rowptr[cg][m]; j < rowptr[cg][m + 1]; ++j) {
+            const int col = colidx[cg][j];
+            const int kc = col % g.KW, kr = (col / g.KW) % g.KH, ic = col / (g.KW * g.KH);
+            if (ic < ic_lo || ic >= ic_hi) continue;
+            Rec rec;
+            rec.val = values[cg][j];
+            rec.m0 = kM0Mode | (uint32_t)(4 * (gl * g.KW + kc));
+            rows[(ic - ic_lo) * g.KH + kr].push_back(rec);
+          }
+        }
+        // rows -> groups of at most kMaxSlots records
+        std::vector<Group> groups;
+        for (int r = 0; r < rows_per_blk; ++r) {
+          const std::vector<Rec> &rr = rows[r];
+          const int icl = r / g.KH, kr = r % g.KH;
+          const uint32_t off = (uint32_t)(((size_t)icl * t.plane_ch_floats + (size_t)kr * t.RS) * 4);
+          for (size_t b = 0; b < rr.size(); b += kMaxSlots) {
+            Group gr;
+            gr.lds_off = off;
+            gr.recs.assign(rr.begin() + b, rr.begin() + std::min(rr.size(), b + kMaxSlots));
+            groups.push_back(gr);
+          }
+        }
+        std::stable_sort(groups.begin(), groups.end(), [](const Group &a, const Group &b) {
+          return a.recs.size() > b.recs.size();
+        });
+        const size_t unit = ws.words.size();
+        ws.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk] = (int32_t)unit;
+        const int tg = (int)groups.size();
+        ws.words.resize(unit + (size_t)(tg + 3) * kChunkDwords, 0u);
+        uint32_t *hdr = &ws.words[unit];
+        hdr[0] = (uint32_t)tg;
+        for (int n = 1; n <= kMaxSlots; ++n) {
+          int cum = 0;
+          for (const Group &gr : groups) cum += ((int)gr.recs.size() >= n) ? 1 : 0;
+          hdr[n] = (uint32_t)(64 * (cum + 3));
+        }
+        for (int k = 0; k < tg; ++k) {
+          uint32_t *c = &ws.words[unit + (size_t)(k + 1) * kChunkDwords];
+          const Group &gr = groups[k];
+          const int n = (int)gr.recs.size();
+          c[0] = gr.lds_off;
+          c[1] = (uint32_t)n;
+          for (int s = 0; s < n; ++s) {
+            const int slot = kMaxSlots - n + s;
+            uint32_t bits;
+            std::memcpy(&bits, &gr.recs[s].val, 4);
+            c[2 + 2 * slot] = bits;
+            c[3 + 2 * slot] = gr.recs[s].m0;
+          }
+          ws.n_records += n;
+        }
+        ws.n_groups += tg;
+        ws.n_slots += (long)tg * kMaxSlots;
+      }
+    }
+  }
+  return ws;
+}
+
+}  // namespace escoin
