@@ -1,128 +1,233 @@
 #!/usr/bin/env python3
-"""Generates stream_loop_asm.inc: the gfx950 inline-asm body of the tiled kernel's weight-stream
-loop (see sconv_tiled.hip and stream_builder.h for the stream format).
+"""Generates stream_loop_asm.inc: the gfx950 inline-asm pieces of the tiled kernel
+(sconv_tiled.hip; stream format in stream_builder.h).
 
-Why generated: the loop is software-pipelined three chunks deep (SGPR set p holds the group
-being applied, set p+1 the next group whose input quad is being fetched from LDS, set p+2 is
-the target of the scalar prefetch), so the body exists in 3 phases x 7 record counts with
-literal register numbers in every instruction.
+Design notes (all measured on MI355X, tools/probes/):
+  * fp32 FMA throughput needs v_pk_fma_f32 (plain v_fma_f32 tops out near 57 TFLOP/s, packed
+    near 125) and >= 2 waves per SIMD;
+  * the accumulator a nonzero updates is data dependent -> GPR-index mode (M0) with VDST and
+    VSRC2 relative; works with VOP3P;
+  * scalar loads cannot stream the weights (about two 64-byte lines in flight per wave, ~750
+    cycles per line): the stream comes in through the VECTOR memory path instead, 64 chunks of
+    48 bytes held lane-distributed in 12 VGPRs (lane l = chunk l mod 64), refilled half a window
+    (32 lanes, EXEC-masked) at a time 32 chunks ahead of use, and single dwords are broadcast
+    with v_readlane_b32;
+  * a lane owns two pixel quads (tiles A and B) so one record = 4 v_pk_fma_f32.
 
-Register contract with sconv_tiled.hip (the C++ part is compiled with amdgpu_num_vgpr(NV), so
-the compiler never touches v[NV..255]):
-    v[VA..VA+2]     LDS address temporaries, one per phase
-    v[X0..X0+11]    three input quads (phase p -> X0+4p), 64-bit aligned for v_pk_fma_f32
-    v[ACC..ACC+191] accumulators, addressed RELATIVE through M0 (GPR-index mode, VDST+VSRC2)
-    s[OFF]          prefetch cursor (byte offset into the unit), s[SET0+16k..] chunk sets,
-    s[HDR..HDR+15]  unit header (END_n at HDR+n)
-Operands supplied by the compiler: %[base] (SGPR pair: unit address), %[lb] (VGPR: lane's LDS
-byte address of plane row 0 / channel 0).
+Register contract with sconv_tiled.hip (C++ compiled with amdgpu_num_vgpr(NV): the compiler
+never touches v[NV..255]):
+    v32,v33          LDS addresses of the next group's quads (tile A, tile B)
+    v[36:51]         input quads: phase p -> A: v[36+8p..], B: v[40+8p..]
+    v[52:63]         stream window (dword d of the chunks in v[52+d])
+    v[64:159]        tile-A accumulators, v[160:255] tile-B accumulators (same index + 96)
+    s[32:59]         scratch owned by the asm (cursor, bucket ends, values, ...)
+Operands: %[k] chunk cursor (in/out), %[plo]/%[phi] address of the next half window to request
+(in/out), %[lbA]/%[lbB] the lane's LDS byte addresses of its two quads (plane row 0, channel
+0), %[voff] (lane & 31) * 48.
 
     python gen_stream_loop.py > stream_loop_asm.inc
 """
 import sys
 
-NV = 32          # VGPRs left to the compiler
-VA = 32          # 3 address temporaries
-X0 = 36          # 3 x 4 input quad registers
-ACC = 48         # 192 accumulators
-NACC = 192
-OFF = 32         # SGPR: prefetch cursor
-SET = [36, 52, 68]
-HDR = 84
-MAX_SLOTS = 7
+NV = 32
+VA, VB = 32, 33
+XA = [36, 44]
+XB = [40, 48]
+SW = 52                      # stream window registers
+ACC_A, ACC_B = 64, 160
+NACC_TILE = 96
+CUR = [32, 33]               # chunk cursor, alternating by phase
+STOP = 34
+HDR = 35
+IX, IX2 = 36, 37
+VAL = [38, 40]               # SGPR pairs (value, junk)
+END0 = 41                    # END_n in s[END0 + n], n = 1..8
+UEND = 50
+TMP = 51
+PTR = 54                     # s[54:55]
+EXS = 56                     # s[56:57] saved exec
+MAX_SLOTS = 8
+HALF_BYTES = 32 * 48
 
 
-def body(n, p, nop, idx_op):
-    cur, nxt, ld = p, (p + 1) % 3, (p + 2) % 3
+def refill(L, cur):
+    """Cursor `cur` (SGPR number) sits on a multiple of 32: wait for its half window and
+    request the next one into the lanes of the half that was just consumed."""
+    A = L.append
+    A("s_waitcnt vmcnt(0)")
+    A("s_bitcmp1_b32 s%d, 5" % cur)
+    A("s_cselect_b32 exec_lo, -1, 0")
+    A("s_cselect_b32 exec_hi, 0, -1")
+    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d]" % (SW, SW + 3, PTR, PTR + 1))
+    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d] offset:16" % (SW + 4, SW + 7, PTR, PTR + 1))
+    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d] offset:32" % (SW + 8, SW + 11, PTR, PTR + 1))
+    A("s_mov_b64 exec, s[%d:%d]" % (EXS, EXS + 1))
+    A("s_add_u32 s%d, s%d, %d" % (PTR, PTR, HALF_BYTES))
+    A("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1))
+
+
+def x_prefetch(L, cur, xset):
+    """Issue the LDS reads of group `cur`'s two quads into X set `xset` (index 0: no relocation)."""
+    A = L.append
+    A("v_readlane_b32 s%d, v%d, s%d" % (HDR, SW, cur))
+    A("s_set_gpr_idx_idx 0")
+    A("v_add_u32 v%d, s%d, %%[lbA]" % (VA, HDR))
+    A("v_add_u32 v%d, s%d, %%[lbB]" % (VB, HDR))
+    A("ds_read_b128 v[%d:%d], v%d" % (XA[xset], XA[xset] + 3, VA))
+    A("ds_read_b128 v[%d:%d], v%d" % (XB[xset], XB[xset] + 3, VB))
+
+
+def pk4(L, val, p):
+    A = L.append
+    for (acc, x) in ((ACC_A, XA[p]), (ACC_A + 2, XA[p] + 2), (ACC_B, XB[p]), (ACC_B + 2, XB[p] + 2)):
+        A("v_pk_fma_f32 v[%d:%d], s[%d:%d], v[%d:%d], v[%d:%d] op_sel_hi:[0,1,1]"
+          % (acc, acc + 1, val, val + 1, x, x + 1, acc, acc + 1))
+
+
+def entry(L, n, p):
+    """Bucket entry / stop handler: bucket exhausted -> next bucket; window crossing -> refill and
+    redo the X prefetch; then recompute the stop and fall into the loop."""
+    A = L.append
+    c = CUR[p]
+    A("ESC_E%d_%d_%%=:" % (n, p))
+    A("s_cmp_eq_u32 s%d, s%d" % (c, END0 + n))
+    A("s_cbranch_scc1 ESC_E%d_%d_%%=" % (n - 1, p))
+    A("s_and_b32 s%d, s%d, 31" % (TMP, c))
+    A("s_cmp_lg_u32 s%d, 0" % TMP)
+    A("s_cbranch_scc1 ESC_S%d_%d_%%=" % (n, p))
+    refill(L, c)
+    A("s_waitcnt vmcnt(3)")          # the half holding chunk c landed; the new request may fly
+    x_prefetch(L, c, p)
+    A("ESC_S%d_%d_%%=:" % (n, p))
+    A("s_or_b32 s%d, s%d, 31" % (TMP, c))
+    A("s_add_u32 s%d, s%d, 1" % (TMP, TMP))
+    A("s_min_u32 s%d, s%d, s%d" % (STOP, TMP, END0 + n))
+
+
+def loop_body(L, n, p):
+    A = L.append
+    c, nx = CUR[p], CUR[1 - p]
+    A("ESC_L%d_%d_%%=:" % (n, p))
+    A("v_readlane_b32 s%d, v%d, s%d" % (IX, SW + 1, c))
+    A("v_readlane_b32 s%d, v%d, s%d" % (VAL[0], SW + 3, c))
+    A("s_add_u32 s%d, s%d, 1" % (nx, c))
+    if n > 4:
+        A("v_readlane_b32 s%d, v%d, s%d" % (IX2, SW + 2, c))
+    if n > 1:
+        A("v_readlane_b32 s%d, v%d, s%d" % (VAL[1], SW + 4, c))
+    A("s_waitcnt lgkmcnt(0)")
+    for r in range(n):
+        ix = IX if r < 4 else IX2
+        if r % 4 != 0:
+            A("s_lshr_b32 s%d, s%d, 8" % (ix, ix))
+        A("s_set_gpr_idx_idx s%d" % ix)
+        pk4(L, VAL[r % 2], p)
+        if r + 2 < n:
+            A("v_readlane_b32 s%d, v%d, s%d" % (VAL[r % 2], SW + 3 + r + 2, c))
+        if r == 0:
+            x_prefetch(L, nx, 1 - p)
+    A("s_cmp_eq_u32 s%d, s%d" % (nx, STOP))
+    A("s_cbranch_scc1 ESC_E%d_%d_%%=" % (n, 1 - p))
+    if p == 1:
+        A("s_branch ESC_L%d_0_%%=" % n)
+
+
+def generate():
     L = []
     A = L.append
-    A("ESC_E%d_%d_%%=:" % (n, p))
-    A("s_cmp_eq_u32 s%d, s%d" % (OFF, HDR + n))
-    A("s_cbranch_scc1 ESC_E%d_%d_%%=" % (n - 1, p))
+    c0 = CUR[0]
+    A("s_mov_b64 s[%d:%d], exec" % (EXS, EXS + 1))
+    A("s_mov_b32 s%d, %%[k]" % c0)
+    A("s_mov_b32 s%d, %%[plo]" % PTR)
+    A("s_mov_b32 s%d, %%[phi]" % (PTR + 1))
+    # unit header chunk (may sit on a window crossing)
+    A("s_and_b32 s%d, s%d, 31" % (TMP, c0))
+    A("s_cmp_lg_u32 s%d, 0" % TMP)
+    A("s_cbranch_scc1 ESC_H_%=")
+    refill(L, c0)
+    A("s_waitcnt vmcnt(3)")
+    A("ESC_H_%=:")
+    A("v_readlane_b32 s%d, v%d, s%d" % (UEND, SW, c0))
+    for n in range(1, MAX_SLOTS + 1):
+        A("v_readlane_b32 s%d, v%d, s%d" % (END0 + n, SW + n, c0))
+    A("s_add_u32 s%d, s%d, 1" % (c0, c0))
+    A("s_nop 3")                                   # SALU write -> v_readlane lane select
+    A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % c0)   # index set before every use
+    x_prefetch(L, c0, 0)
+    for n in range(MAX_SLOTS, 0, -1):
+        # the entries for both phases, then the two loop bodies
+        entry(L, n, 0)
+        A("s_branch ESC_L%d_0_%%=" % n)
+        entry(L, n, 1)
+        A("s_branch ESC_L%d_1_%%=" % n)
+        loop_body(L, n, 0)
+        loop_body(L, n, 1)
+    A("ESC_E0_1_%=:")
+    A("s_mov_b32 s%d, s%d" % (CUR[0], CUR[1]))
+    A("ESC_E0_0_%=:")
+    A("s_set_gpr_idx_off")
     A("s_waitcnt lgkmcnt(0)")
-    # next group's input quad: address = lane base + row offset (index 0: no relocation)
-    A("s_set_gpr_idx_idx 0")
-    A("v_add_u32 v%d, s%d, %%[lb]" % (VA + nxt, SET[nxt]))
-    A("ds_read_b128 v[%d:%d], v%d" % (X0 + 4 * nxt, X0 + 4 * nxt + 3, VA + nxt))
-    # scalar prefetch two chunks ahead
-    A("s_load_dwordx16 s[%d:%d], %%[base], s%d" % (SET[ld], SET[ld] + 15, OFF))
-    A("s_add_u32 s%d, s%d, 64" % (OFF, OFF))
-    x = X0 + 4 * cur
-    for slot in range(MAX_SLOTS - n, MAX_SLOTS):
-        sv = SET[cur] + 2 + 2 * slot
-        if idx_op == "idx":
-            A("s_set_gpr_idx_idx s%d" % (sv + 1))
-        else:
-            A("s_mov_b32 m0, s%d" % (sv + 1))
-        if nop:
-            A("s_nop 0")
-        A("v_pk_fma_f32 v[%d:%d], s[%d:%d], v[%d:%d], v[%d:%d] op_sel_hi:[0,1,1]"
-          % (ACC, ACC + 1, sv, sv + 1, x, x + 1, ACC, ACC + 1))
-        A("v_pk_fma_f32 v[%d:%d], s[%d:%d], v[%d:%d], v[%d:%d] op_sel_hi:[0,1,1]"
-          % (ACC + 2, ACC + 3, sv, sv + 1, x + 2, x + 3, ACC + 2, ACC + 3))
-    if p == 2:
-        A("s_branch ESC_E%d_0_%%=" % n)
+    A("s_mov_b32 %%[k], s%d" % CUR[0])
+    A("s_mov_b32 %%[plo], s%d" % PTR)
+    A("s_mov_b32 %%[phi], s%d" % (PTR + 1))
     return L
 
 
-def generate(nop=False, idx_op="idx"):
+def generate_init():
+    """Requests half window 0 (chunks 0..31 of the wave's stream) into lanes 0..31."""
     L = []
     A = L.append
-    # prologue: header + first two groups, cursor at chunk 3
-    A("s_load_dwordx16 s[%d:%d], %%[base], 0x0" % (HDR, HDR + 15))
-    A("s_load_dwordx16 s[%d:%d], %%[base], 0x40" % (SET[0], SET[0] + 15))
-    A("s_load_dwordx16 s[%d:%d], %%[base], 0x80" % (SET[1], SET[1] + 15))
-    A("s_movk_i32 s%d, 0xc0" % OFF)
-    A("s_waitcnt lgkmcnt(0)")
-    A("v_add_u32 v%d, s%d, %%[lb]" % (VA, SET[0]))
-    A("ds_read_b128 v[%d:%d], v%d" % (X0, X0 + 3, VA))
-    A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % OFF)   # index value irrelevant until set
-    for n in range(MAX_SLOTS, 0, -1):
-        for p in range(3):
-            L.extend(body(n, p, nop, idx_op))
-    for p in range(3):
-        A("ESC_E0_%d_%%=:" % p)
-    A("s_set_gpr_idx_off")
-    A("s_waitcnt lgkmcnt(0)")
+    A("s_mov_b64 s[%d:%d], exec" % (EXS, EXS + 1))
+    A("s_mov_b32 s%d, %%[plo]" % PTR)
+    A("s_mov_b32 s%d, %%[phi]" % (PTR + 1))
+    A("s_mov_b32 exec_lo, -1")
+    A("s_mov_b32 exec_hi, 0")
+    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d]" % (SW, SW + 3, PTR, PTR + 1))
+    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d] offset:16" % (SW + 4, SW + 7, PTR, PTR + 1))
+    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d] offset:32" % (SW + 8, SW + 11, PTR, PTR + 1))
+    A("s_mov_b64 exec, s[%d:%d]" % (EXS, EXS + 1))
+    A("s_add_u32 s%d, s%d, %d" % (PTR, PTR, HALF_BYTES))
+    A("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1))
+    A("s_mov_b32 %%[plo], s%d" % PTR)
+    A("s_mov_b32 %%[phi], s%d" % (PTR + 1))
     return L
 
 
 def clobbers():
-    c = ["memory", "scc", "m0"]
-    c += ["s%d" % i for i in range(OFF, HDR + 16)]
-    c += ["v%d" % i for i in range(VA, ACC + NACC)]
+    c = ["memory", "scc", "m0", "exec"]
+    c += ["s%d" % i for i in range(32, 60)]
+    c += ["v%d" % i for i in range(VA, 256)]
     return c
+
+
+def emit_macro(out, name, lines):
+    out.write("#define %s \\\n" % name)
+    for ln in lines:
+        out.write('  "%s\\n" \\\n' % ln)
+    out.write('  ""\n')
 
 
 def main():
     out = sys.stdout
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
-    out.write("#define ESC_NV %d\n#define ESC_ACC %d\n#define ESC_NACC %d\n" % (NV, ACC, NACC))
-    for name, kw in (("ESC_STREAM_LOOP_ASM", dict(nop=False, idx_op="idx")),
-                     ("ESC_STREAM_LOOP_ASM_NOP", dict(nop=True, idx_op="idx")),
-                     ("ESC_STREAM_LOOP_ASM_M0", dict(nop=True, idx_op="m0"))):
-        out.write("#define %s \\\n" % name)
-        lines = generate(**kw)
-        for ln in lines:
-            out.write('  "%s\\n" \\\n' % ln)
-        out.write('  ""\n')
+    out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
+    emit_macro(out, "ESC_STREAM_LOOP_ASM", generate())
+    emit_macro(out, "ESC_STREAM_INIT_ASM", generate_init())
     out.write("#define ESC_STREAM_LOOP_CLOBBERS \\\n  ")
     out.write(", ".join('"%s"' % c for c in clobbers()))
     out.write("\n")
-    # accumulator zeroing and per-quad read-out
-    out.write("#define ESC_ZERO_ACC_ASM \\\n")
-    for i in range(ACC, ACC + NACC, 2):
-        out.write('  "v_mov_b64 v[%d:%d], 0\\n" \\\n' % (i, i + 1))
-    out.write('  ""\n')
+    zero = ["v_mov_b64 v[%d:%d], 0" % (i, i + 1) for i in range(ACC_A, 256, 2)]
+    emit_macro(out, "ESC_ZERO_ACC_ASM", zero)
     out.write("#define ESC_ACC_CLOBBERS ")
-    out.write(", ".join('"v%d"' % i for i in range(ACC, ACC + NACC)))
+    out.write(", ".join('"v%d"' % i for i in range(ACC_A, 256)))
     out.write("\n")
-    # ESC_READ_QUAD(q): asm text moving accumulator quad q into %0..%3
-    out.write("#define ESC_NQUADS %d\n" % (NACC // 4))
-    for q in range(NACC // 4):
-        r = ACC + 4 * q
-        out.write('#define ESC_READ_QUAD_%d "v_mov_b32 %%0, v%d\\n v_mov_b32 %%1, v%d\\n '
-                  'v_mov_b32 %%2, v%d\\n v_mov_b32 %%3, v%d\\n"\n' % (q, r, r + 1, r + 2, r + 3))
+    # ESC_READ_QUAD_<tile>_<q>: asm text moving accumulator quad q of a tile into %0..%3
+    out.write("#define ESC_NQUADS_TILE %d\n" % (NACC_TILE // 4))
+    for tile, base in ((0, ACC_A), (1, ACC_B)):
+        for q in range(NACC_TILE // 4):
+            r = base + 4 * q
+            out.write('#define ESC_READ_QUAD_%d_%d "v_mov_b32 %%0, v%d\\n v_mov_b32 %%1, v%d\\n '
+                      'v_mov_b32 %%2, v%d\\n v_mov_b32 %%3, v%d\\n"\n' % (tile, q, r, r + 1, r + 2, r + 3))
 
 
 if __name__ == "__main__":

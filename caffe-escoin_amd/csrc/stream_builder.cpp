@@ -22,9 +22,8 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) 
   t.KH = g.KH;
   t.S4 = next_pow2((g.W + 3) / 4);
   t.RS = 4 * t.S4;
-  t.rows_per_wave = 64 / t.S4;
-  t.G = std::min(32, kMaxAccRegs / (4 * g.KW));   // KW=1:32  KW=3:16  KW=5:9
-  if (g.KW == 5) t.G = 8;
+  t.rows_per_slab = 64 / t.S4;
+  t.G = kAccRegsPerTile / (4 * g.KW);            // KW=1:24  KW=2:12  KW=3:8  KW=4:6  KW=5:4
   t.G = std::min(t.G, std::max(1, g.Mg));
   t.n_ocg = (g.Mg + t.G - 1) / t.G;
   t.waves = waves_per_wg;
@@ -32,15 +31,15 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) 
   while (t.oc_waves * 2 <= waves_per_wg && t.oc_waves < t.n_ocg) t.oc_waves *= 2;
   t.pix_waves = waves_per_wg / t.oc_waves;
   t.n_ocblk = (t.n_ocg + t.oc_waves - 1) / t.oc_waves;
-  const int rows_per_wg = t.pix_waves * t.rows_per_wave;
-  if (g.OH <= rows_per_wg) {
+  t.rows_per_wg = t.pix_waves * kTilesPerLane * t.rows_per_slab;
+  if (g.OH <= t.rows_per_wg) {
     t.band_mode = false;
     t.tr = g.OH;
-    t.nseg = rows_per_wg / g.OH;
+    t.nseg = t.rows_per_wg / g.OH;
     t.bands = 1;
   } else {
     t.band_mode = true;
-    t.tr = rows_per_wg;
+    t.tr = t.rows_per_wg;
     t.nseg = 1;
     t.bands = (g.OH + t.tr - 1) / t.tr;
   }
@@ -54,7 +53,7 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) 
   // balance the blocks: same number of blocks, evenly sized
   t.n_icb = (g.Cg + icb - 1) / icb;
   t.icb = (g.Cg + t.n_icb - 1) / t.n_icb;
-  t.lds_bytes = t.icb * per_ch;
+  t.planes_bytes = t.icb * per_ch;
   t.ok = true;
   return t;
 }
@@ -62,7 +61,7 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) 
 namespace {
 struct Rec {
   float val;
-  uint32_t m0;
+  uint8_t idx;
 };
 struct Group {
   uint32_t lds_off;
@@ -75,11 +74,16 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
                           const std::vector<std::vector<int>> &colidx,
                           const std::vector<std::vector<float>> &values) {
   WeightStream ws;
-  ws.unit_off.assign((size_t)g.group * t.n_ocg * t.n_icb, 0);
+  const size_t n_units = (size_t)g.group * t.n_ocg * t.n_icb;
+  ws.unit_off.assign(n_units, 0);
+  ws.unit_chunks.assign(n_units, 0);
   const int rows_per_blk = t.icb * g.KH;
   std::vector<std::vector<Rec>> rows(rows_per_blk);   // records per (ic_local, kr)
   for (int cg = 0; cg < g.group; ++cg) {
     for (int ocg = 0; ocg < t.n_ocg; ++ocg) {
+      // chunk indices are relative to the start of this (cg, ocg) wave-stream: the kernel keeps
+      // one running chunk cursor across the ic blocks
+      const size_t stream_start = ws.words.size();
       for (int blk = 0; blk < t.n_icb; ++blk) {
         for (auto &r : rows) r.clear();
         const int ic_lo = blk * t.icb, ic_hi = std::min(g.Cg, ic_lo + t.icb);
@@ -92,11 +96,10 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
             if (ic < ic_lo || ic >= ic_hi) continue;
             Rec rec;
             rec.val = values[cg][j];
-            rec.m0 = kM0Mode | (uint32_t)(4 * (gl * g.KW + kc));
+            rec.idx = (uint8_t)(4 * (gl * g.KW + kc));
             rows[(ic - ic_lo) * g.KH + kr].push_back(rec);
           }
         }
-        // rows -> groups of at most kMaxSlots records
         std::vector<Group> groups;
         for (int r = 0; r < rows_per_blk; ++r) {
           const std::vector<Rec> &rr = rows[r];
@@ -113,36 +116,38 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
           return a.recs.size() > b.recs.size();
         });
         const size_t unit = ws.words.size();
-        ws.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk] = (int32_t)unit;
+        const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
+        ws.unit_off[ui] = (int32_t)unit;
         const int tg = (int)groups.size();
-        ws.words.resize(unit + (size_t)(tg + 3) * kChunkDwords, 0u);
+        ws.unit_chunks[ui] = tg + 1;
+        ws.max_unit_chunks = std::max(ws.max_unit_chunks, tg + 1);
+        ws.words.resize(unit + (size_t)(tg + 1) * kChunkDwords, 0u);
+        const uint32_t hdr_idx = (uint32_t)((unit - stream_start) / kChunkDwords);
         uint32_t *hdr = &ws.words[unit];
-        hdr[0] = (uint32_t)tg;
+        hdr[0] = hdr_idx + 1 + (uint32_t)tg;
         for (int n = 1; n <= kMaxSlots; ++n) {
           int cum = 0;
           for (const Group &gr : groups) cum += ((int)gr.recs.size() >= n) ? 1 : 0;
-          hdr[n] = (uint32_t)(64 * (cum + 3));
+          hdr[n] = hdr_idx + 1 + (uint32_t)cum;
         }
         for (int k = 0; k < tg; ++k) {
           uint32_t *c = &ws.words[unit + (size_t)(k + 1) * kChunkDwords];
           const Group &gr = groups[k];
           const int n = (int)gr.recs.size();
           c[0] = gr.lds_off;
-          c[1] = (uint32_t)n;
+          c[11] = (uint32_t)n;
           for (int s = 0; s < n; ++s) {
-            const int slot = kMaxSlots - n + s;
-            uint32_t bits;
-            std::memcpy(&bits, &gr.recs[s].val, 4);
-            c[2 + 2 * slot] = bits;
-            c[3 + 2 * slot] = gr.recs[s].m0;
+            c[1 + s / 4] |= (uint32_t)gr.recs[s].idx << (8 * (s % 4));
+            std::memcpy(&c[3 + s], &gr.recs[s].val, 4);
           }
           ws.n_records += n;
         }
         ws.n_groups += tg;
-        ws.n_slots += (long)tg * kMaxSlots;
       }
     }
   }
+  // the kernel prefetches up to two half-windows (64 chunks) past the cursor
+  ws.words.resize(ws.words.size() + (size_t)(kWindowChunks + 32) * kChunkDwords, 0u);
   return ws;
 }
 

@@ -14,6 +14,7 @@
 #include "stream_builder.h"
 
 using namespace escoin;
+static const int kAccAll = kTilesPerLane * kAccRegsPerTile;
 
 static unsigned rng_state = 12345;
 static float frand() {
@@ -78,7 +79,8 @@ static int run(const Case &cs) {
     for (int cg = 0; cg < g.group; ++cg)
       for (int ocblk = 0; ocblk < t.n_ocblk; ++ocblk) {
         // per-wave accumulators: [wave][lane][192]
-        std::vector<float> acc((size_t)t.waves * 64 * kMaxAccRegs, 0.f);
+        std::vector<float> acc((size_t)t.waves * 64 * kAccAll, 0.f);
+        std::vector<uint32_t> cursor(t.waves, 0u);   // running chunk cursor per wave
         for (int blk = 0; blk < t.n_icb; ++blk) {
           // ---- fill ----
           std::fill(lds.begin(), lds.end(), 0.f);
@@ -104,40 +106,44 @@ static int run(const Case &cs) {
             const int pw = wave % t.pix_waves, ow_ = wave / t.pix_waves;
             const int ocg = ocblk * t.oc_waves + ow_;
             if (ocg >= t.n_ocg) continue;
-            const uint32_t *unit = &ws.words[ws.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk]];
-            const uint32_t *hdr = unit;
-            uint32_t s_off = 64 * 3;
-            int k = 0;
+            // the wave's stream is continuous over the ic blocks: chunk indices are relative to
+            // the first unit of (cg, ocg)
+            const uint32_t *wstream = &ws.words[ws.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb]];
+            uint32_t &k = cursor[wave];
+            const uint32_t *hdr = wstream + (size_t)k * kChunkDwords;
+            if (&ws.words[ws.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk]] != hdr) {
+              printf("cursor does not sit on the unit header\n"); return 3;
+            }
+            const uint32_t uend = hdr[0];
+            ++k;
             for (int n = kMaxSlots; n >= 1; --n) {
-              while (s_off != hdr[n]) {
-                const uint32_t *c = unit + (size_t)(k + 1) * kChunkDwords;
-                if ((int)c[1] != n) { printf("bucket order broken\n"); return 3; }
+              while (k != hdr[n]) {
+                const uint32_t *c = wstream + (size_t)k * kChunkDwords;
+                if ((int)c[11] != n) { printf("bucket order broken\n"); return 3; }
                 for (int lane = 0; lane < 64; ++lane) {
-                  const int fr = pw * t.rows_per_wave + lane / t.S4;
-                  const int seg = fr / t.tr, yl = fr % t.tr, j = lane % t.S4;
-                  // idle lanes read a valid but meaningless address: clamp like the kernel does
-                  size_t base = ((size_t)seg * t.plane_rows + yl) * t.RS + 4 * j;
-                  if (seg >= t.nseg) base = 0;
-                  const size_t a = base + c[0] / 4;
-                  float *A = &acc[((size_t)wave * 64 + lane) * kMaxAccRegs];
-                  for (int s = kMaxSlots - n; s < kMaxSlots; ++s) {
-                    float v;
-                    std::memcpy(&v, &c[2 + 2 * s], 4);
-                    const uint32_t m0 = c[3 + 2 * s];
-                    if ((m0 & 0xF000u) != kM0Mode) { printf("bad m0 mode\n"); return 3; }
-                    const int idx = m0 & 0xFF;
-                    if (idx + 3 >= kMaxAccRegs) { printf("acc idx out of range\n"); return 3; }
-                    for (int e = 0; e < 4; ++e) {
-                      const float xv = (a + e < lds.size()) ? lds[a + e] : 0.f;
-                      A[idx + e] = std::fmaf(v, xv, A[idx + e]);
+                  for (int tl = 0; tl < 2; ++tl) {
+                    const int fr = (pw * 2 + tl) * t.rows_per_slab + lane / t.S4;
+                    const int seg = fr / t.tr, yl = fr % t.tr, j = lane % t.S4;
+                    size_t base = ((size_t)seg * t.plane_rows + yl) * t.RS + 4 * j;
+                    if (seg >= t.nseg) base = 0;     // idle lanes read a valid but meaningless address
+                    const size_t a = base + c[0] / 4;
+                    float *A = &acc[((size_t)wave * 64 + lane) * kAccAll + tl * kAccRegsPerTile];
+                    for (int s = 0; s < n; ++s) {
+                      float v;
+                      std::memcpy(&v, &c[3 + s], 4);
+                      const int idx = (c[1 + s / 4] >> (8 * (s % 4))) & 0xFF;
+                      if (idx + 3 >= kAccRegsPerTile) { printf("acc idx out of range\n"); return 3; }
+                      for (int e = 0; e < 4; ++e) {
+                        const float xv = (a + e < lds.size()) ? lds[a + e] : 0.f;
+                        A[idx + e] = std::fmaf(v, xv, A[idx + e]);
+                      }
                     }
                   }
                 }
                 ++k;
-                s_off += 64;
               }
             }
-            if (k != (int)hdr[0]) { printf("walked %d of %u groups\n", k, hdr[0]); return 3; }
+            if (k != uend) { printf("walked to %u, unit ends at %u\n", k, uend); return 3; }
           }
         }
         // ---- epilogue ----
@@ -149,31 +155,33 @@ static int run(const Case &cs) {
             const int m = ocg * t.G + gl;
             if (m >= g.Mg) break;
             const int oc = cg * g.Mg + m;
-            for (int lane = 0; lane < 64; ++lane) {
-              const int fr = pw * t.rows_per_wave + lane / t.S4;
-              const int seg = fr / t.tr, yl = fr % t.tr, j = lane % t.S4;
-              if (seg >= t.nseg) continue;
-              int n, y;
-              if (t.band_mode) { n = tile / t.bands; y = (tile % t.bands) * t.tr + yl; }
-              else { n = tile * t.nseg + seg; y = yl; }
-              if (n >= g.N || y >= g.OH) continue;
-              for (int e = 0; e < 4; ++e) {
-                const int xo = 4 * j + e;
-                if (xo >= g.OW) continue;
-                float sum = 0.f;
-                for (int kc = 0; kc < g.KW; ++kc) {
-                  const int pos = e + kc - g.pad_w;   // position relative to own quad
-                  int src_lane = lane, el = pos;
-                  if (pos < 0) { if (j == 0) continue; src_lane = lane - 1; el = pos + 4; }
-                  else if (pos > 3) { if (j == t.S4 - 1) continue; src_lane = lane + 1; el = pos - 4; }
-                  sum += acc[((size_t)wave * 64 + src_lane) * kMaxAccRegs + 4 * (gl * g.KW + kc) + el];
+            for (int tl = 0; tl < 2; ++tl)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int fr = (pw * 2 + tl) * t.rows_per_slab + lane / t.S4;
+                const int seg = fr / t.tr, yl = fr % t.tr, j = lane % t.S4;
+                if (seg >= t.nseg) continue;
+                int n, y;
+                if (t.band_mode) { n = tile / t.bands; y = (tile % t.bands) * t.tr + yl; }
+                else { n = tile * t.nseg + seg; y = yl; }
+                if (n >= g.N || y >= g.OH) continue;
+                for (int e = 0; e < 4; ++e) {
+                  const int xo = 4 * j + e;
+                  if (xo >= g.OW) continue;
+                  float sum = 0.f;
+                  for (int kc = 0; kc < g.KW; ++kc) {
+                    const int pos = e + kc - g.pad_w;   // position relative to own quad
+                    int src_lane = lane, el = pos;
+                    if (pos < 0) { if (j == 0) continue; src_lane = lane - 1; el = pos + 4; }
+                    else if (pos > 3) { if (j == t.S4 - 1) continue; src_lane = lane + 1; el = pos - 4; }
+                    sum += acc[((size_t)wave * 64 + src_lane) * kAccAll + tl * kAccRegsPerTile +
+                               4 * (gl * g.KW + kc) + el];
+                  }
+                  sum += bias[oc];
+                  const size_t o = (((size_t)n * g.M + oc) * g.OH + y) * g.OW + xo;
+                  got[o] = sum;
+                  written[o]++;
                 }
-                sum += bias[oc];
-                const size_t o = (((size_t)n * g.M + oc) * g.OH + y) * g.OW + xo;
-                got[o] = sum;
-                written[o]++;
               }
-            }
           }
         }
       }
@@ -185,10 +193,10 @@ static int run(const Case &cs) {
   }
   const double rel = maxerr / std::fmax(1e-6, maxref);
   printf("N%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
-         "groups=%ld recs=%ld slot_use=%.2f rel_err=%.2e\n",
+         "groups=%ld recs=%ld recs/group=%.2f rel_err=%.2e\n",
          cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.S4, t.G,
-         t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.lds_bytes, ws.n_groups,
-         ws.n_records, ws.n_groups ? (double)ws.n_records / (double)ws.n_slots : 0.0, rel);
+         t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes, ws.n_groups,
+         ws.n_records, ws.n_groups ? (double)ws.n_records / (double)ws.n_groups : 0.0, rel);
   return rel <= 1e-5 ? 0 : 1;
 }
 
