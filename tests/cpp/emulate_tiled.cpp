@@ -202,22 +202,22 @@ static int run(const Case &cs) {
 
 int main() {
   const Case cases[] = {
-      {3, 8, 7, 7, 40, 3, 3, 1, 1, 1, 0.9f, 4, 65536},      // res5-like: whole images per WG
-      {2, 16, 14, 14, 24, 3, 3, 1, 1, 1, 0.9f, 4, 65536},   // res4-like
-      {2, 6, 28, 28, 20, 3, 3, 1, 1, 1, 0.8f, 4, 8192},     // res3-like, several ic blocks
-      {2, 5, 56, 56, 16, 3, 3, 1, 1, 1, 0.9f, 4, 65536},    // res2-like: band mode
+      {3, 8, 7, 7, 40, 3, 3, 1, 1, 1, 0.9f, 8, 65536},      // res5-like: whole images per WG
+      {2, 16, 14, 14, 24, 3, 3, 1, 1, 1, 0.9f, 8, 65536},   // res4-like
+      {2, 6, 28, 28, 20, 3, 3, 1, 1, 1, 0.8f, 8, 8192},     // res3-like, several ic blocks
+      {2, 5, 56, 56, 16, 3, 3, 1, 1, 1, 0.9f, 8, 65536},    // res2-like: band mode
       {2, 5, 56, 56, 70, 3, 3, 1, 1, 1, 0.9f, 8, 65536},    // 8 waves, oc tail
-      {2, 8, 27, 27, 16, 5, 5, 2, 2, 2, 0.8f, 4, 65536},    // alex conv2-like: 5x5, groups
-      {3, 12, 13, 13, 20, 3, 3, 1, 1, 2, 0.8f, 4, 65536},   // alex conv4-like
-      {2, 20, 12, 12, 50, 5, 5, 0, 0, 1, 0.5f, 4, 65536},   // lenet conv2: valid 5x5
-      {2, 24, 28, 28, 33, 1, 1, 0, 0, 1, 0.95f, 4, 65536},  // googlenet 1x1
-      {1, 3, 20, 20, 8, 3, 3, 2, 2, 1, 0.5f, 4, 65536},     // pad 2 with 3x3 (OH > H)
-      {2, 4, 9, 70, 8, 3, 3, 1, 1, 1, 0.6f, 4, 65536},      // wide: S4 = 32
-      {1, 4, 5, 200, 4, 3, 1, 1, 0, 1, 0.5f, 4, 65536},     // KW = 1 with KH = 3, S4 = 64
-      {2, 4, 6, 6, 4, 2, 2, 1, 1, 1, 0.3f, 4, 65536},       // even kernel
-      {1, 2, 4, 4, 3, 3, 3, 1, 1, 1, 0.0f, 4, 65536},       // dense tiny
-      {1, 2, 4, 4, 3, 3, 3, 1, 1, 1, 1.0f, 4, 65536},       // all pruned
-      {5, 64, 7, 7, 48, 3, 3, 1, 1, 1, 0.5f, 4, 65536},     // dense-ish rows: groups split at 7 slots
+      {2, 8, 27, 27, 16, 5, 5, 2, 2, 2, 0.8f, 8, 65536},    // alex conv2-like: 5x5, groups
+      {3, 12, 13, 13, 20, 3, 3, 1, 1, 2, 0.8f, 8, 65536},   // alex conv4-like
+      {2, 20, 12, 12, 50, 5, 5, 0, 0, 1, 0.5f, 8, 65536},   // lenet conv2: valid 5x5
+      {2, 24, 28, 28, 33, 1, 1, 0, 0, 1, 0.95f, 8, 65536},  // googlenet 1x1
+      {1, 3, 20, 20, 8, 3, 3, 2, 2, 1, 0.5f, 8, 65536},     // pad 2 with 3x3 (OH > H)
+      {2, 4, 9, 70, 8, 3, 3, 1, 1, 1, 0.6f, 8, 65536},      // wide: S4 = 32
+      {1, 4, 5, 200, 4, 3, 1, 1, 0, 1, 0.5f, 8, 65536},     // KW = 1 with KH = 3, S4 = 64
+      {2, 4, 6, 6, 4, 2, 2, 1, 1, 1, 0.3f, 8, 65536},       // even kernel
+      {1, 2, 4, 4, 3, 3, 3, 1, 1, 1, 0.0f, 8, 65536},       // dense tiny
+      {1, 2, 4, 4, 3, 3, 3, 1, 1, 1, 1.0f, 8, 65536},       // all pruned
+      {5, 64, 7, 7, 48, 3, 3, 1, 1, 1, 0.5f, 8, 65536},     // dense-ish rows: groups split at 7 slots
   };
   int bad = 0;
   for (const Case &c : cases) bad += run(c) != 0;
