@@ -46,6 +46,7 @@ UEND = 50
 TMP = 51
 PTR = 54                     # s[54:55]
 EXS = 56                     # s[56:57] saved exec
+IXT = [58, 59]               # alternating shifted-index temporaries
 MAX_SLOTS = 8
 HALF_BYTES = 32 * 48
 
@@ -116,11 +117,19 @@ def loop_body(L, n, p):
     if n > 1:
         A("v_readlane_b32 s%d, v%d, s%d" % (VAL[1], SW + 4, c))
     A("s_waitcnt lgkmcnt(0)")
+
+    def ixreg(r):
+        if r == 0:
+            return IX
+        if r == 4:
+            return IX2
+        return IXT[r % 2]
+
     for r in range(n):
-        ix = IX if r < 4 else IX2
-        if r % 4 != 0:
-            A("s_lshr_b32 s%d, s%d, 8" % (ix, ix))
-        A("s_set_gpr_idx_idx s%d" % ix)
+        A("s_set_gpr_idx_idx s%d" % ixreg(r))
+        if r + 1 < n and (r + 1) % 4 != 0:
+            # next record's index byte, computed while this record's FMAs issue
+            A("s_lshr_b32 s%d, s%d, %d" % (ixreg(r + 1), IX if r + 1 < 4 else IX2, 8 * ((r + 1) % 4)))
         pk4(L, VAL[r % 2], p)
         if r + 2 < n:
             A("v_readlane_b32 s%d, v%d, s%d" % (VAL[r % 2], SW + 3 + r + 2, c))
@@ -195,7 +204,7 @@ def generate_init():
 
 def clobbers():
     c = ["memory", "scc", "m0", "exec"]
-    c += ["s%d" % i for i in range(32, 60)]
+    c += ["s%d" % i for i in range(32, 64)]
     c += ["v%d" % i for i in range(VA, 256)]
     return c
 
