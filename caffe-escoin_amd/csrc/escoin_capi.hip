@@ -169,7 +169,8 @@ int escoin_plan_destroy(escoin_plan *plan) {
 
 int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
   if (!p || !key) return fail(ESCOIN_EINVAL, "null argument");
-  if (p->aligned) return fail(ESCOIN_ESTATE, "options must be set before weight_align/set_csr");
+  if (p->aligned && strcmp(key, "conv_mode") != 0)
+    return fail(ESCOIN_ESTATE, "this option must be set before weight_align/set_csr");
   if (!strcmp(key, "kernel")) {
     if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_TILED)
       return fail(ESCOIN_EINVAL, "unknown kernel id");
