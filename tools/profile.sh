@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel stats + separate PMC passes for the bench.
+#   gpurun -- 'bash tools/profile.sh r01 resnet50'
+# Writes gpurun_out/prof_<tag>/...; tools/save_profile.py condenses it into profiles/.
+set -u
+TAG=${1:-r01}
+WL=${2:-resnet50}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_${TAG}_${WL}
+mkdir -p $OUT
+ARGS="bench.py --workload $WL --steps 5 --warmup 2 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_stats.json 2> $OUT/bench_stats.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > /dev/null 2> $OUT/pmc_write.log
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > /dev/null 2> $OUT/pmc_sq.log
+find $OUT -name "*.csv" | head -20

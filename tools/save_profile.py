@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_<tag>_<workload>/ directory (tools/profile.sh) into small committed
+files under profiles/: the rocprofv3 --stats table with kernel names shortened, and the per-kernel
+PMC sums (FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them, per launch).
+
+    python tools/save_profile.py gpurun_out/prof_r01_resnet50 r01_resnet50
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"(escoin::)?(escoin_\w+(<[^>]*>)?)", name)
+    if m:
+        return m.group(2)
+    return (name[:60] + "...") if len(name) > 63 else name
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    os.makedirs("profiles", exist_ok=True)
+    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        with open("profiles/%s_kernel_stats.csv" % tag, "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py ... (tools/profile.sh)\n")
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows[:12]:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                            r["Percentage"], r["MinNs"], r["MaxNs"]])
+    out = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+        for fn in files:
+            for r in csv.DictReader(open(fn)):
+                k = short(r["Kernel_Name"])
+                if not k.startswith("escoin"):
+                    continue
+                d = out.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
+                d[0] += float(r["Counter_Value"])
+                d[1] += 1
+    summary = {}
+    for k, cs in out.items():
+        summary[k] = {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(1, v[1])} for c, v in cs.items()}
+    with open("profiles/%s_pmc.json" % tag, "w") as f:
+        json.dump(summary, f, indent=1, sort_keys=True)
+    print(json.dumps(summary, indent=1, sort_keys=True)[:3000])
+
+
+if __name__ == "__main__":
+    main()
