@@ -17,7 +17,7 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) 
   // epilogue shifts: s = kc - pad_w must satisfy |s| <= 4 (one neighbouring quad)
   if (g.KW < 1 || g.KW > 5 || g.pad_w > 4 || g.KW - 1 - g.pad_w > 4) return t;
   if (g.W > 256 || g.OH < 1 || g.OW < 1) return t;
-  if (waves_per_wg != 4 && waves_per_wg != 8) return t;
+  if (waves_per_wg != 1 && waves_per_wg != 2 && waves_per_wg != 4 && waves_per_wg != 8) return t;
   t.KW = g.KW;
   t.KH = g.KH;
   t.S4 = next_pow2((g.W + 3) / 4);
