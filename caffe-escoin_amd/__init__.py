@@ -20,7 +20,7 @@ from . import shard, synth  # noqa: F401  (re-exported)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libescoin_hip.so")
 
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED, KERNEL_DENSE = 0, 1, 2, 3
 CONV_MODE_SCONV, CONV_MODE_SCONV_PAR = 2, 3
 
 # every symbol include/escoin.h declares (tests check the library exports all of them)

@@ -57,6 +57,8 @@ static void free_device(escoin_plan *p) {
   if (p->d_vals) (void)hipFree(p->d_vals);
   if (p->d_stream) (void)hipFree(p->d_stream);
   if (p->d_stream_ptr) (void)hipFree(p->d_stream_ptr);
+  if (p->d_dense_w) (void)hipFree(p->d_dense_w);
+  p->d_dense_w = nullptr;
   p->d_rowptr = p->d_taps = p->d_stream_ptr = nullptr;
   p->d_vals = nullptr;
   p->d_stream = nullptr;
@@ -102,6 +104,26 @@ static int upload(escoin_plan *p, hipStream_t stream) {
   ESCOIN_HIP_TRY(hipStreamSynchronize(stream));  // host vectors die at scope exit
 
   p->tiled = TiledConfig();
+  // dense path: asked for explicitly, or through the reference's gate on group 0's density
+  // (nz_num_[0] / (M/g * kernel_dim) > 0.2, base_conv_layer.cpp:750, :805)
+  const double density0 = (double)p->colidx[0].size() / ((double)g.Mg * g.kdim);
+  p->use_dense = p->kernel_choice == ESCOIN_KERNEL_DENSE ||
+                 (p->kernel_choice == ESCOIN_KERNEL_AUTO && p->dense_gate && density0 > 0.2);
+  if (p->use_dense) {
+    std::vector<float> dense((size_t)g.d.M * g.kdim, 0.f);
+    for (int grp = 0; grp < g.d.group; ++grp)
+      for (int m = 0; m < g.Mg; ++m)
+        for (int j = p->rowptr[grp][m]; j < p->rowptr[grp][m + 1]; ++j)
+          dense[((size_t)grp * g.Mg + m) * g.kdim + p->colidx[grp][j]] = p->values[grp][j];
+    ESCOIN_HIP_TRY(hipMalloc(&p->d_dense_w, sizeof(float) * dense.size()));
+    p->device_bytes += sizeof(float) * dense.size();
+    ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_dense_w, dense.data(), sizeof(float) * dense.size(),
+                                  hipMemcpyHostToDevice, stream));
+    ESCOIN_HIP_TRY(hipStreamSynchronize(stream));
+    p->kernel_name = dense_kernel_name();
+    p->aligned = true;
+    return ESCOIN_OK;
+  }
   const bool want_tiled = p->kernel_choice == ESCOIN_KERNEL_TILED ||
                           (p->kernel_choice == ESCOIN_KERNEL_AUTO && tiled_supported(g));
   if (want_tiled) {
@@ -172,7 +194,7 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
   if (p->aligned && strcmp(key, "conv_mode") != 0)
     return fail(ESCOIN_ESTATE, "this option must be set before weight_align/set_csr");
   if (!strcmp(key, "kernel")) {
-    if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_TILED)
+    if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_DENSE)
       return fail(ESCOIN_EINVAL, "unknown kernel id");
     p->kernel_choice = value;
   } else if (!strcmp(key, "conv_mode")) {
@@ -299,6 +321,7 @@ int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_de
     return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
   if (n_images == 0) return ESCOIN_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (p->use_dense) return launch_dense(p, bottom_dev, bias_dev, top_dev, n_images, s);
   if (p->tiled.enabled) return launch_tiled(p, bottom_dev, bias_dev, top_dev, n_images, s);
   return launch_generic(p, bottom_dev, bias_dev, top_dev, n_images, s);
 }

@@ -76,6 +76,10 @@ struct escoin_plan {
   int *d_stream_ptr = nullptr;    // per (oc-wave-group, ic-block) offsets into d_stream
   size_t stream_words = 0;
 
+  // dense fallback (fp32 MFMA implicit GEMM)
+  float *d_dense_w = nullptr;     // [M][Cg*KH*KW]
+  bool use_dense = false;
+
   size_t device_bytes = 0;
   std::string kernel_name = "(not aligned)";
 };
@@ -93,6 +97,11 @@ int tiled_build(escoin_plan *p, hipStream_t stream);  // fills p->tiled, uploads
 int launch_tiled(const escoin_plan *p, const float *bottom, const float *bias, float *top,
                  int n_images, hipStream_t stream);
 const char *tiled_kernel_name(const escoin_plan *p);
+
+// dense_mfma.hip
+int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, float *top,
+                 int n_images, hipStream_t stream);
+const char *dense_kernel_name();
 
 }  // namespace escoin
 

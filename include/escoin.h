@@ -63,6 +63,7 @@ extern "C" {
 #define ESCOIN_KERNEL_AUTO 0
 #define ESCOIN_KERNEL_GENERIC 1 /* one lane = one output pixel, CSR order kept    */
 #define ESCOIN_KERNEL_TILED 2   /* LDS-staged tiles, row-grouped weight stream    */
+#define ESCOIN_KERNEL_DENSE 3   /* implicit-GEMM on the fp32 matrix cores (MFMA)  */
 
 /* Geometry of one ConvolutionLayer: what LayerSetUp/Reshape derive from
  * ConvolutionParameter + the bottom shape (base_conv_layer.cpp:276-530). */
@@ -100,9 +101,10 @@ ESCOIN_API int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **pl
 ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
 
 /* Options: "kernel" = ESCOIN_KERNEL_*, "conv_mode" = ESCOIN_CONV_MODE_*,
- * "dense_gate" = 0/1 (1: mimic the reference's per-layer gate that sends
- * density(group 0) > 0.2 to the dense path, base_conv_layer.cpp:750-755; the dense
- * path here is the same kernels run on the unpruned CSR). Must precede weight_align. */
+ * "dense_gate" = 0/1 (1: reproduce the reference's per-layer gate that sends
+ * density(group 0) > 0.2 to the dense GEMM path, base_conv_layer.cpp:750-755,805-811;
+ * here the dense path is the fp32-MFMA implicit-GEMM kernel, ESCOIN_KERNEL_DENSE).
+ * "kernel" and "dense_gate" must precede weight_align. */
 ESCOIN_API int escoin_plan_set_option(escoin_plan *plan, const char *key, int value);
 
 /* WeightAlign(): dense blobs_[0] (M x C/g x KH x KW, zeros = pruned) -> per-group CSR

@@ -37,7 +37,7 @@ def _run(pkg, torch, desc, w, x, bias, kernel):
 
 
 def _kernels(pkg):
-    return [pkg.KERNEL_GENERIC, pkg.KERNEL_AUTO]
+    return [pkg.KERNEL_GENERIC, pkg.KERNEL_AUTO, pkg.KERNEL_DENSE]
 
 
 @pytest.mark.parametrize("path", golden_params())
@@ -268,3 +268,35 @@ def test_linearity_and_batch_independence_full_size(pkg, synth, torch_cuda):
     assert float((fr - fx[:8]).abs().max()) / scale <= TOL
     plan.close()
     ref.close()
+
+
+def test_dense_gate_follows_the_reference_threshold(pkg, oracle, synth, torch_cuda):
+    """dense_gate=1 reproduces forward_gpu_sconv's gate (base_conv_layer.cpp:750-755): density of
+    group 0 > 0.2 -> dense (MFMA) path, otherwise the sparse kernels; same numbers either way."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    for sparsity, want_dense in ((0.70, True), (0.80, False), (0.90, False), (0.0, True)):
+        s = synth.shape("gate", 3, 32, 14, 14, 40, 3, pad=1, sparsity=sparsity)
+        w, b, x = synth.pruned_weights(s, 1), synth.bias_vector(s, 2), synth.activations(s, 3)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w)
+        want = oracle.conv_forward(g, x, w, b, gate=False)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+        plan.set_option("dense_gate", 1)
+        plan.weight_align(w)
+        assert ("dense_mfma" in plan.kernel_name) == want_dense, (sparsity, plan.kernel_name)
+        got = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+        assert rel_err(got, want) <= TOL
+        plan.close()
+    # the gate looks at group 0 only (reference quirk 5): dense group 0, sparse group 1
+    s = synth.shape("gate2", 2, 16, 9, 9, 16, 3, pad=1, group=2, sparsity=0.9)
+    w = synth.pruned_weights(s, 4)
+    w[:8] = synth.uniform(9, w[:8].size).reshape(w[:8].shape)      # group 0 fully dense
+    x = synth.activations(s, 5)
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, group=2)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    plan.set_option("dense_gate", 1)
+    plan.weight_align(w)
+    assert "dense_mfma" in plan.kernel_name
+    got = plan.forward(torch.from_numpy(x).to(dev), None).cpu().numpy()
+    assert rel_err(got, oracle.conv_forward(g, x, w, None, gate=False)) <= TOL
+    plan.close()
