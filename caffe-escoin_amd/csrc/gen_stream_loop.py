@@ -230,6 +230,37 @@ def main():
     out.write("#define ESC_ACC_CLOBBERS ")
     out.write(", ".join('"v%d"' % i for i in range(ACC_A, 256)))
     out.write("\n")
+    # ESC_EPI3_<tile>_<g>: 3x3 / pad 1 epilogue of output channel g of a tile, in place on the
+    # accumulators: out[e] = C[e] + L[e-1] + R[e+1] (L, C, R = the kc = 0, 1, 2 classes); the two
+    # elements that live in the neighbouring quad come through DPP row_shr/row_shl with
+    # bound_ctrl (0 at the row edge).  %4..%7 are per-lane 0/1 masks applied first when the
+    # MASKED variant is used (columns >= W hold garbage when W is not a multiple of 4).
+    for tile, base in ((0, ACC_A), (1, ACC_B)):
+        for g in range(NACC_TILE // 12):
+            L0 = base + 12 * g
+            C0 = L0 + 4
+            R0 = L0 + 8
+            for masked in (False, True):
+                lines = []
+                if masked:
+                    for cls in (L0, C0, R0):
+                        for e in range(4):
+                            lines.append("v_mul_f32 v%d, v%d, %%%d" % (cls + e, cls + e, 4 + e))
+                lines += [
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 0, C0 + 0, R0 + 1),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 1, C0 + 1, L0 + 0),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 1, C0 + 1, R0 + 2),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 2, C0 + 2, L0 + 1),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 2, C0 + 2, R0 + 3),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 3, C0 + 3, L0 + 2),
+                    "v_add_f32_dpp v%d, v%d, v%d row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                    % (C0 + 0, L0 + 3, C0 + 0),
+                    "v_add_f32_dpp v%d, v%d, v%d row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                    % (C0 + 3, R0 + 0, C0 + 3),
+                    "v_mov_b32 %%0, v%d" % (C0 + 0), "v_mov_b32 %%1, v%d" % (C0 + 1),
+                    "v_mov_b32 %%2, v%d" % (C0 + 2), "v_mov_b32 %%3, v%d" % (C0 + 3),
+                ]
+                emit_macro(out, "ESC_EPI3%s_%d_%d" % ("M" if masked else "", tile, g), lines)
     # ESC_READ_QUAD_<tile>_<q>: asm text moving accumulator quad q of a tile into %0..%3
     out.write("#define ESC_NQUADS_TILE %d\n" % (NACC_TILE // 4))
     for tile, base in ((0, ACC_A), (1, ACC_B)):
