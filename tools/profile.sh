@@ -8,7 +8,7 @@ WL=${2:-resnet50}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${WL}
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 ARGS="bench.py --workload $WL --steps 5 --warmup 2 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_stats.json 2> $OUT/bench_stats.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log
