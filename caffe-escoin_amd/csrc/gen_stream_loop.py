@@ -83,6 +83,11 @@ def x_issue(L, p):
         return
     A("s_set_gpr_idx_idx 0")
     A("v_add_u32 v%d, s%d, %%[lbA]" % (VA, HDR[p]))
+    if "band" in ABL:
+        # band mode: tile B is the next 64-quad slab of the same plane, 1 KiB further
+        A("ds_read_b128 v[%d:%d], v%d" % (XA[p], XA[p] + 3, VA))
+        A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[p], XB[p] + 3, VA))
+        return
     A("v_add_u32 v%d, s%d, %%[lbB]" % (VB, HDR[p]))
     A("ds_read_b128 v[%d:%d], v%d" % (XA[p], XA[p] + 3, VA))
     A("ds_read_b128 v[%d:%d], v%d" % (XB[p], XB[p] + 3, VB))
@@ -168,6 +173,10 @@ def loop_body(L, n, p):
                 A(pre.pop(0))
     while pre:
         A(pre.pop(0))
+    if "nop4" in ABL:
+        A("s_nop 0"); A("s_nop 0"); A("s_nop 0"); A("s_nop 0")
+    if "vnop4" in ABL:
+        A("v_nop"); A("v_nop"); A("v_nop"); A("v_nop")
     A("s_cmp_eq_u32 s%d, s%d" % (CUR[q], STOP))
     A("s_cbranch_scc1 ESC_E%d_%d_%%=" % (n, q))
     if p == 1:
@@ -259,7 +268,10 @@ def main():
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
     emit_macro(out, "ESC_STREAM_LOOP_ASM", generate())
-    for name in ("nopk", "noxp", "noval", "noidx"):
+    ABL.add("band")
+    emit_macro(out, "ESC_STREAM_LOOP_ASM_BAND", generate())
+    ABL.discard("band")
+    for name in ("nopk", "noxp", "nop4", "vnop4"):
         ABL.add(name)
         emit_macro(out, "ESC_STREAM_LOOP_ASM_" + name.upper(), generate())
         ABL.discard(name)
