@@ -271,10 +271,13 @@ def main():
     ABL.add("band")
     emit_macro(out, "ESC_STREAM_LOOP_ASM_BAND", generate())
     ABL.discard("band")
+    # timing-only ablations (wrong results), compiled in with -DESCOIN_ABLATIONS
+    out.write("#ifdef ESCOIN_ABLATIONS\n")
     for name in ("nopk", "noxp", "nop4", "vnop4"):
         ABL.add(name)
         emit_macro(out, "ESC_STREAM_LOOP_ASM_" + name.upper(), generate())
         ABL.discard(name)
+    out.write("#endif\n")
     emit_macro(out, "ESC_STREAM_INIT_ASM", generate_init())
     out.write("#define ESC_STREAM_LOOP_CLOBBERS \\\n  ")
     out.write(", ".join('"%s"' % c for c in clobbers()))
