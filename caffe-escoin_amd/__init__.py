@@ -18,7 +18,8 @@ import numpy as np
 from . import shard, synth  # noqa: F401  (re-exported)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libescoin_hip.so")
+# ESCOIN_LIB: A/B experiments against another build of the library
+LIB_PATH = os.environ.get("ESCOIN_LIB") or os.path.join(_HERE, "libescoin_hip.so")
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED, KERNEL_DENSE = 0, 1, 2, 3
 CONV_MODE_SCONV, CONV_MODE_SCONV_PAR = 2, 3

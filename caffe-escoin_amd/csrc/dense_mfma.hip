@@ -63,14 +63,16 @@ __global__ void __launch_bounds__(256) escoin_dense_mfma_kernel(DenseArgs a) {
   const float *wrow = a.w + ((size_t)cg * a.Mg + (am_ok ? m0 + am : 0)) * a.K;
 
   f32x16 acc0 = {0}, acc1 = {0};
-  for (int k0 = 0; k0 < a.K; k0 += kBK) {
-    // gather this step's operands into registers
-    float av0 = 0.f, av1 = 0.f;
+  float av0, av1, bv[4];
+  // gathers one k-step's operands into registers (software pipelined: the loads of step k+1 fly
+  // under the MFMAs of step k)
+  auto gather = [&](int k0) {
+    av0 = 0.f;
+    av1 = 0.f;
     if (am_ok) {
       if (k0 + ak < a.K) av0 = wrow[k0 + ak];
       if (k0 + ak + 1 < a.K) av1 = wrow[k0 + ak + 1];
     }
-    float bv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int k = k0 + kb + 2 * q;
@@ -85,12 +87,16 @@ __global__ void __launch_bounds__(256) escoin_dense_mfma_kernel(DenseArgs a) {
       }
       bv[q] = v;
     }
+  };
+  gather(0);
+  for (int k0 = 0; k0 < a.K; k0 += kBK) {
     __syncthreads();                                // previous step's fragments are consumed
     sA[ak][am] = av0;
     sA[ak + 1][am] = av1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) sB[kb + 2 * q][p_local] = bv[q];
     __syncthreads();
+    if (k0 + kBK < a.K) gather(k0 + kBK);
 #pragma unroll
     for (int kk = 0; kk < kBK; kk += 2) {
       // 32x32x2: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]

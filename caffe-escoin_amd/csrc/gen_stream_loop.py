@@ -38,20 +38,17 @@ ACC_A, ACC_B = 64, 160
 NACC_TILE = 96
 CUR = [32, 33]               # chunk cursor, alternating by phase
 STOP = 34
-HDR = [35, 49]               # row offset of the group phase p will apply (read two groups ahead)
-TMP = 36
-IXT = [37, 38]               # alternating shifted-index temporaries
-END0 = 39                    # END_n in s[END0 + n], n = 1..8
-UEND = 48
-PTR = 50                     # s[50:51]
-EXS = 52                     # s[52:53] saved exec
-# per-phase scalar copies of a group's chunk: phase p holds the group being applied, the other
-# phase is filled (v_readlane, one group ahead) while this one is consumed
-IX = [54, 74]
-IX2 = [55, 75]
-VALS = [[56 + 2 * r for r in range(8)], [76 + 2 * r for r in range(8)]]   # SGPR pairs (value, junk)
+HDR = 35
+IX, IX2 = 36, 37
+VAL = [38, 40]               # SGPR pairs (value, junk)
+END0 = 41                    # END_n in s[END0 + n], n = 1..8
+UEND = 50
+TMP = 51
+PTR = 54                     # s[54:55]
+EXS = 56                     # s[56:57] saved exec
+IXT = [58, 59]               # alternating shifted-index temporaries
 MAX_SLOTS = 8
-ABL = set()                  # ablation switches for timing experiments (see main())
+ABL = set()                  # generator switches: 'band' + timing-only ablations (see main())
 HALF_BYTES = 32 * 48
 
 
@@ -71,36 +68,22 @@ def refill(L, cur):
     A("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1))
 
 
-def hdr_read(L, cur, p):
-    L.append("v_readlane_b32 s%d, v%d, s%d" % (HDR[p], SW, cur))
-
-
-def x_issue(L, p):
-    """LDS reads of the two quads of the group phase p will apply (row offset in s[HDR[p]]) into
-    X set p (index 0: the address adds must not be relocated)."""
+def x_prefetch(L, cur, xset):
+    """Issue the LDS reads of group `cur`'s two quads into X set `xset` (index 0: no relocation)."""
     A = L.append
+    A("v_readlane_b32 s%d, v%d, s%d" % (HDR, SW, cur))
     if "noxp" in ABL:
         return
     A("s_set_gpr_idx_idx 0")
-    A("v_add_u32 v%d, s%d, %%[lbA]" % (VA, HDR[p]))
+    A("v_add_u32 v%d, s%d, %%[lbA]" % (VA, HDR))
     if "band" in ABL:
         # band mode: tile B is the next 64-quad slab of the same plane, 1 KiB further
-        A("ds_read_b128 v[%d:%d], v%d" % (XA[p], XA[p] + 3, VA))
-        A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[p], XB[p] + 3, VA))
+        A("ds_read_b128 v[%d:%d], v%d" % (XA[xset], XA[xset] + 3, VA))
+        A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[xset], XB[xset] + 3, VA))
         return
-    A("v_add_u32 v%d, s%d, %%[lbB]" % (VB, HDR[p]))
-    A("ds_read_b128 v[%d:%d], v%d" % (XA[p], XA[p] + 3, VA))
-    A("ds_read_b128 v[%d:%d], v%d" % (XB[p], XB[p] + 3, VB))
-
-
-def scalars_read(L, cur, p, nvals):
-    """Broadcast chunk `cur`'s index bytes and first `nvals` values into phase p's SGPR set."""
-    A = L.append
-    A("v_readlane_b32 s%d, v%d, s%d" % (IX[p], SW + 1, cur))
-    if nvals > 4:
-        A("v_readlane_b32 s%d, v%d, s%d" % (IX2[p], SW + 2, cur))
-    for r in range(nvals):
-        A("v_readlane_b32 s%d, v%d, s%d" % (VALS[p][r], SW + 3 + r, cur))
+    A("v_add_u32 v%d, s%d, %%[lbB]" % (VB, HDR))
+    A("ds_read_b128 v[%d:%d], v%d" % (XA[xset], XA[xset] + 3, VA))
+    A("ds_read_b128 v[%d:%d], v%d" % (XB[xset], XB[xset] + 3, VB))
 
 
 def pk4(L, val, p):
@@ -125,10 +108,7 @@ def entry(L, n, p):
     A("s_cbranch_scc1 ESC_S%d_%d_%%=" % (n, p))
     refill(L, c)
     A("s_waitcnt vmcnt(3)")          # the half holding chunk c landed; the new request may fly
-    hdr_read(L, c, p)
-    scalars_read(L, c, p, n)
-    hdr_read(L, CUR[1 - p], 1 - p)   # chunk c + 1: the body issues its LDS reads first thing
-    x_issue(L, p)
+    x_prefetch(L, c, p)
     A("ESC_S%d_%d_%%=:" % (n, p))
     A("s_or_b32 s%d, s%d, 31" % (TMP, c))
     A("s_add_u32 s%d, s%d, 1" % (TMP, TMP))
@@ -136,49 +116,41 @@ def entry(L, n, p):
 
 
 def loop_body(L, n, p):
-    """Applies group c (scalars in phase p's SGPR set, quads in X set p).  Invariant on entry:
-    CUR[p] = c, CUR[q] = c + 1, HDR[q] = row offset of group c + 1, phase q's scalar set and
-    X set free.  Under the FMAs it issues group c + 1's LDS reads, broadcasts group c + 1's
-    scalars into phase q's set and group c + 2's row offset into HDR[p]."""
     A = L.append
-    q = 1 - p
+    c, nx = CUR[p], CUR[1 - p]
     A("ESC_L%d_%d_%%=:" % (n, p))
-    A("s_add_u32 s%d, s%d, 2" % (CUR[p], CUR[p]))      # c + 2: lane select of the header read-ahead
-    A("s_waitcnt lgkmcnt(0)")                             # group c's quads landed
-    x_issue(L, q)
+    A("v_readlane_b32 s%d, v%d, s%d" % (IX, SW + 1, c))
+    A("v_readlane_b32 s%d, v%d, s%d" % (VAL[0], SW + 3, c))
+    A("s_add_u32 s%d, s%d, 1" % (nx, c))
+    if n > 4:
+        A("v_readlane_b32 s%d, v%d, s%d" % (IX2, SW + 2, c))
+    if n > 1:
+        A("v_readlane_b32 s%d, v%d, s%d" % (VAL[1], SW + 4, c))
+    A("s_waitcnt lgkmcnt(0)")
 
     def ixreg(r):
         if r == 0:
-            return IX[p]
+            return IX
         if r == 4:
-            return IX2[p]
+            return IX2
         return IXT[r % 2]
 
-    pre = ["v_readlane_b32 s%d, v%d, s%d" % (IX[q], SW + 1, CUR[q])]
-    if n > 4:
-        pre.append("v_readlane_b32 s%d, v%d, s%d" % (IX2[q], SW + 2, CUR[q]))
-    if "noval" not in ABL:
-        for r in range(n):
-            pre.append("v_readlane_b32 s%d, v%d, s%d" % (VALS[q][r], SW + 3 + r, CUR[q]))
-    pre.append("v_readlane_b32 s%d, v%d, s%d" % (HDR[p], SW, CUR[p]))
-    per = (len(pre) + n - 1) // n
     for r in range(n):
-        if "noidx" not in ABL:
-            A("s_set_gpr_idx_idx s%d" % ixreg(r))
-            if r + 1 < n and (r + 1) % 4 != 0:
-                A("s_lshr_b32 s%d, s%d, %d" % (ixreg(r + 1), IX[p] if r + 1 < 4 else IX2[p], 8 * ((r + 1) % 4)))
-        pk4(L, VALS[p][r], p)
-        for _ in range(per):
-            if pre:
-                A(pre.pop(0))
-    while pre:
-        A(pre.pop(0))
+        A("s_set_gpr_idx_idx s%d" % ixreg(r))
+        if r + 1 < n and (r + 1) % 4 != 0:
+            # next record's index byte, computed while this record's FMAs issue
+            A("s_lshr_b32 s%d, s%d, %d" % (ixreg(r + 1), IX if r + 1 < 4 else IX2, 8 * ((r + 1) % 4)))
+        pk4(L, VAL[r % 2], p)
+        if r + 2 < n:
+            A("v_readlane_b32 s%d, v%d, s%d" % (VAL[r % 2], SW + 3 + r + 2, c))
+        if r == 0:
+            x_prefetch(L, nx, 1 - p)
     if "nop4" in ABL:
         A("s_nop 0"); A("s_nop 0"); A("s_nop 0"); A("s_nop 0")
     if "vnop4" in ABL:
         A("v_nop"); A("v_nop"); A("v_nop"); A("v_nop")
-    A("s_cmp_eq_u32 s%d, s%d" % (CUR[q], STOP))
-    A("s_cbranch_scc1 ESC_E%d_%d_%%=" % (n, q))
+    A("s_cmp_eq_u32 s%d, s%d" % (nx, STOP))
+    A("s_cbranch_scc1 ESC_E%d_%d_%%=" % (n, 1 - p))
     if p == 1:
         A("s_branch ESC_L%d_0_%%=" % n)
 
@@ -204,12 +176,7 @@ def generate():
     A("s_add_u32 s%d, s%d, 1" % (c0, c0))
     A("s_nop 3")                                   # SALU write -> v_readlane lane select
     A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % c0)   # index set before every use
-    A("s_add_u32 s%d, s%d, 1" % (CUR[1], c0))
-    hdr_read(L, c0, 0)
-    scalars_read(L, c0, 0, MAX_SLOTS)
-    A("s_nop 1")
-    hdr_read(L, CUR[1], 1)
-    x_issue(L, 0)
+    x_prefetch(L, c0, 0)
     for n in range(MAX_SLOTS, 0, -1):
         # the entries for both phases, then the two loop bodies
         entry(L, n, 0)
@@ -251,7 +218,7 @@ def generate_init():
 
 def clobbers():
     c = ["memory", "scc", "m0", "exec"]
-    c += ["s%d" % i for i in range(32, 96)]
+    c += ["s%d" % i for i in range(32, 64)]
     c += ["v%d" % i for i in range(VA, 256)]
     return c
 
