@@ -23,12 +23,18 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) 
   t.S4 = next_pow2((g.W + 3) / 4);
   t.RS = 4 * t.S4;
   t.rows_per_slab = 64 / t.S4;
-  t.G = kAccRegsPerTile / (4 * g.KW);            // KW=1:24  KW=2:12  KW=3:8  KW=4:6  KW=5:4
-  t.G = std::min(t.G, std::max(1, g.Mg));
-  t.n_ocg = (g.Mg + t.G - 1) / t.G;
+  // Output channels per wave.  The accumulator file bounds it (KW=1:24 2:12 3:8 4:6 5:4); within
+  // that bound the channels are spread over as many waves of the workgroup as there are channels
+  // and balanced over the passes: a layer with few output channels then gets a small pixel tile
+  // per workgroup (more workgroups for the same batch) and every wave of it shares one staged
+  // input tile, instead of a few workgroups whose waves each own 24 channels' worth of nothing.
+  const int gmax = kAccRegsPerTile / (4 * g.KW);
   t.waves = waves_per_wg;
   t.oc_waves = 1;
-  while (t.oc_waves * 2 <= waves_per_wg && t.oc_waves < t.n_ocg) t.oc_waves *= 2;
+  while (t.oc_waves * 2 <= waves_per_wg && t.oc_waves * 2 <= std::max(1, g.Mg)) t.oc_waves *= 2;
+  const int passes = (std::max(1, g.Mg) + gmax * t.oc_waves - 1) / (gmax * t.oc_waves);
+  t.G = (std::max(1, g.Mg) + t.oc_waves * passes - 1) / (t.oc_waves * passes);
+  t.n_ocg = (g.Mg + t.G - 1) / t.G;
   t.pix_waves = waves_per_wg / t.oc_waves;
   t.n_ocblk = (t.n_ocg + t.oc_waves - 1) / t.oc_waves;
   t.rows_per_wg = t.pix_waves * kTilesPerLane * t.rows_per_slab;
