@@ -12,8 +12,12 @@ static int next_pow2(int v) {
   return p;
 }
 
-Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) {
+namespace {
+
+// The tiling of one concrete (H, W) cut of the image.
+Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu) {
   Tiling t;
+  t.H = g.H; t.W = g.W; t.OH = g.OH; t.OW = g.OW;
   // epilogue shifts: s = kc - pad_w must satisfy |s| <= 4 (one neighbouring quad)
   if (g.KW < 1 || g.KW > 5 || g.pad_w > 4 || g.KW - 1 - g.pad_w > 4) return t;
   if (g.W > 256 || g.OH < 1 || g.OW < 1) return t;
@@ -43,6 +47,18 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) 
     t.tr = g.OH;
     t.nseg = t.rows_per_wg / g.OH;
     t.bands = 1;
+    // Whole images per workgroup: as many as fit, unless the batch then leaves compute units
+    // without a workgroup.  A workgroup's walk over the weight stream costs the same whether its
+    // lanes are full or not, so the number of rounds (workgroups / CUs) is what counts; among
+    // the choices with the fewest rounds the smallest tile stages the least input per workgroup.
+    const long gy = (long)g.group * t.n_ocblk;
+    auto rounds = [&](int nseg) { return (((long)g.N + nseg - 1) / nseg * gy + n_cu - 1) / n_cu; };
+    const long best = rounds(t.nseg);
+    for (int ns = 1; ns < t.nseg; ++ns)
+      if (rounds(ns) == best) {
+        t.nseg = ns;
+        break;
+      }
   } else {
     t.band_mode = true;
     t.tr = t.rows_per_wg;
@@ -62,6 +78,44 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes) 
   t.planes_bytes = t.icb * per_ch;
   t.ok = true;
   return t;
+}
+
+}  // namespace
+
+Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu) {
+  if (n_cu < 1) n_cu = 256;
+  Tiling best = tile_for(g, waves_per_wg, lds_budget_bytes, n_cu);
+  // A pointwise layer (1x1, no padding) does not care where the rows of an image break: its
+  // H*W pixels are one contiguous run per channel.  When W is not a multiple of 4 the staging
+  // copies (16 bytes per lane) straddle row ends; re-cut the image into rows of W' | H*W that
+  // need the fewest copies (then: best lane use, then longest rows).  Input and output blobs are
+  // the same memory either way.
+  if (g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H && g.OW == g.W &&
+      g.W % 4 != 0) {
+    const int hw = g.H * g.W;
+    auto copies = [](const Tiling &t) { return (long)t.H * ((t.W + 3) / 4); };
+    auto lane_use = [](const Tiling &t) {
+      const double rows = t.band_mode ? (double)t.bands * t.rows_per_wg : (double)t.rows_per_wg;
+      const double used = t.band_mode ? (double)t.H : (double)t.H * (t.rows_per_wg / t.H);
+      return used * t.W / (rows * t.RS);
+    };
+    for (int w = 1; w <= 256 && w <= hw; ++w) {
+      if (hw % w != 0 || w == g.W) continue;
+      ConvGeom c = g;
+      c.W = c.OW = w;
+      c.H = c.OH = hw / w;
+      const Tiling t = tile_for(c, waves_per_wg, lds_budget_bytes, n_cu);
+      if (!t.ok) continue;
+      bool better = !best.ok;
+      if (!better) {
+        const long ca = copies(t), cb = copies(best);
+        const double ua = lane_use(t), ub = lane_use(best);
+        better = ca < cb || (ca == cb && (ua > ub + 1e-9 || (ua > ub - 1e-9 && t.W > best.W)));
+      }
+      if (better) best = t;
+    }
+  }
+  return best;
 }
 
 namespace {

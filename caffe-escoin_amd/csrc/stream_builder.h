@@ -47,6 +47,8 @@ struct ConvGeom {
 struct Tiling {
   bool ok = false;
   int KW = 0, KH = 0;
+  int H = 0, W = 0, OH = 0, OW = 0;  // the image cut the kernel works on (differs from the
+                                     // layer's only for re-cut pointwise layers, see choose_tiling)
   int S4 = 0;            // quads per LDS row (power of two), RS = 4*S4 floats
   int RS = 0;
   int rows_per_slab = 0; // 64 / S4: output rows covered by one 64-quad slab
@@ -69,7 +71,9 @@ struct Tiling {
 // Picks the tiling for a geometry; .ok == false when the tiled kernel does not apply
 // (stride/dilation != 1 are filtered by the caller; here: KW > 5, W > 256, ...).
 // lds_budget_bytes bounds the input planes only; the stream region is added on top.
-Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes);
+// n_cu: compute units of the device (sizes the pixel tile of small layers so that the batch
+// g.N fills the chip).
+Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu = 256);
 
 struct WeightStream {
   std::vector<uint32_t> words;     // all units back to back

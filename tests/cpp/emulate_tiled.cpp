@@ -94,10 +94,10 @@ static int run(const Case &cs) {
               if (n >= g.N) continue;
               for (int pr = 0; pr < t.plane_rows; ++pr) {
                 const int yin = y0 + pr - g.pad_h;
-                if (yin < 0 || yin >= g.H) continue;
-                for (int xx = 0; xx < g.W; ++xx)
+                if (yin < 0 || yin >= t.H) continue;
+                for (int xx = 0; xx < t.W; ++xx)
                   lds[(size_t)icl * t.plane_ch_floats + (size_t)seg * t.plane_seg_floats + pr * t.RS + xx] =
-                      x[(((size_t)n * g.C + cg * g.Cg + ic) * g.H + yin) * g.W + xx];
+                      x[(((size_t)n * g.C + cg * g.Cg + ic) * t.H + yin) * t.W + xx];
               }
             }
           }
@@ -163,10 +163,10 @@ static int run(const Case &cs) {
                 int n, y;
                 if (t.band_mode) { n = tile / t.bands; y = (tile % t.bands) * t.tr + yl; }
                 else { n = tile * t.nseg + seg; y = yl; }
-                if (n >= g.N || y >= g.OH) continue;
+                if (n >= g.N || y >= t.OH) continue;
                 for (int e = 0; e < 4; ++e) {
                   const int xo = 4 * j + e;
-                  if (xo >= g.OW) continue;
+                  if (xo >= t.OW) continue;
                   float sum = 0.f;
                   for (int kc = 0; kc < g.KW; ++kc) {
                     const int pos = e + kc - g.pad_w;   // position relative to own quad
@@ -177,7 +177,7 @@ static int run(const Case &cs) {
                                4 * (gl * g.KW + kc) + el];
                   }
                   sum += bias[oc];
-                  const size_t o = (((size_t)n * g.M + oc) * g.OH + y) * g.OW + xo;
+                  const size_t o = (((size_t)n * g.M + oc) * t.OH + y) * t.OW + xo;
                   got[o] = sum;
                   written[o]++;
                 }
@@ -218,6 +218,10 @@ int main() {
       {1, 2, 4, 4, 3, 3, 3, 1, 1, 1, 0.0f, 8, 65536},       // dense tiny
       {1, 2, 4, 4, 3, 3, 3, 1, 1, 1, 1.0f, 8, 65536},       // all pruned
       {5, 64, 7, 7, 48, 3, 3, 1, 1, 1, 0.5f, 8, 65536},     // dense-ish rows: groups split at 7 slots
+      {7, 40, 14, 14, 16, 1, 1, 0, 0, 1, 0.9f, 8, 65536},   // pointwise, W % 4 != 0: re-cut to 196 x 1
+      {5, 30, 7, 7, 48, 1, 1, 0, 0, 1, 0.9f, 8, 65536},     // pointwise 7x7 -> 49 x 1, few channels/wave
+      {300, 6, 7, 7, 12, 1, 1, 0, 0, 1, 0.8f, 8, 65536},    // batch > CUs: several images per workgroup
+      {3, 6, 13, 13, 10, 1, 1, 0, 0, 2, 0.7f, 8, 65536},    // pointwise 13x13 (169 = 13^2), groups
   };
   int bad = 0;
   for (const Case &c : cases) bad += run(c) != 0;
