@@ -22,7 +22,8 @@ never touches v[NV..255]):
     v[64:159]        tile-A accumulators, v[160:255] tile-B accumulators (same index + 96)
     s[32:59]         scratch owned by the asm (cursor, bucket ends, values, ...)
 Operands: %[k] chunk cursor (in/out), %[plo]/%[phi] address of the next half window to request
-(in/out), %[lbA]/%[lbB] the lane's LDS byte addresses of its two quads (plane row 0, channel
+(in/out), %[pend] 1 while a half-window request may be in flight (in/out; the kernel clears it
+after a full vmcnt drain), %[lbA]/%[lbB] the lane's LDS byte addresses of its two quads (plane row 0, channel
 0), %[voff] (lane & 31) * 48.
 
     python gen_stream_loop.py > stream_loop_asm.inc
@@ -47,6 +48,8 @@ TMP = 51
 PTR = 54                     # s[54:55]
 EXS = 56                     # s[56:57] saved exec
 IXT = [58, 59]               # alternating shifted-index temporaries
+PEND = 52                    # 1: a half-window request may still be in flight
+_label = [0]
 MAX_SLOTS = 8
 ABL = set()                  # generator switches: 'band' + timing-only ablations (see main())
 HALF_BYTES = 32 * 48
@@ -56,7 +59,15 @@ def refill(L, cur):
     """Cursor `cur` (SGPR number) sits on a multiple of 32: wait for its half window and
     request the next one into the lanes of the half that was just consumed."""
     A = L.append
+    # The half holding chunk `cur` was requested 32 chunks ago.  vmcnt completes in order, so
+    # waiting for it also waits for everything issued since -- in particular the next block's
+    # LDS-DMA, which the workgroup issues at every block start.  The kernel drains vmcnt at each
+    # block start anyway and clears PEND there: only a request younger than that drain needs a wait.
+    _label[0] += 1
+    A("s_cmp_eq_u32 s%d, 0" % PEND)
+    A("s_cbranch_scc1 ESC_RW%d_%%=" % _label[0])
     A("s_waitcnt vmcnt(0)")
+    A("ESC_RW%d_%%=:" % _label[0])
     A("s_bitcmp1_b32 s%d, 5" % cur)
     A("s_cselect_b32 exec_lo, -1, 0")
     A("s_cselect_b32 exec_hi, 0, -1")
@@ -66,6 +77,7 @@ def refill(L, cur):
     A("s_mov_b64 exec, s[%d:%d]" % (EXS, EXS + 1))
     A("s_add_u32 s%d, s%d, %d" % (PTR, PTR, HALF_BYTES))
     A("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1))
+    A("s_mov_b32 s%d, 1" % PEND)
 
 
 def x_prefetch(L, cur, xset):
@@ -107,7 +119,6 @@ def entry(L, n, p):
     A("s_cmp_lg_u32 s%d, 0" % TMP)
     A("s_cbranch_scc1 ESC_S%d_%d_%%=" % (n, p))
     refill(L, c)
-    A("s_waitcnt vmcnt(3)")          # the half holding chunk c landed; the new request may fly
     x_prefetch(L, c, p)
     A("ESC_S%d_%d_%%=:" % (n, p))
     A("s_or_b32 s%d, s%d, 31" % (TMP, c))
@@ -157,18 +168,19 @@ def loop_body(L, n, p):
 
 def generate():
     L = []
+    _label[0] = 0
     A = L.append
     c0 = CUR[0]
     A("s_mov_b64 s[%d:%d], exec" % (EXS, EXS + 1))
     A("s_mov_b32 s%d, %%[k]" % c0)
     A("s_mov_b32 s%d, %%[plo]" % PTR)
     A("s_mov_b32 s%d, %%[phi]" % (PTR + 1))
+    A("s_mov_b32 s%d, %%[pend]" % PEND)
     # unit header chunk (may sit on a window crossing)
     A("s_and_b32 s%d, s%d, 31" % (TMP, c0))
     A("s_cmp_lg_u32 s%d, 0" % TMP)
     A("s_cbranch_scc1 ESC_H_%=")
     refill(L, c0)
-    A("s_waitcnt vmcnt(3)")
     A("ESC_H_%=:")
     A("v_readlane_b32 s%d, v%d, s%d" % (UEND, SW, c0))
     for n in range(1, MAX_SLOTS + 1):
@@ -193,6 +205,7 @@ def generate():
     A("s_mov_b32 %%[k], s%d" % CUR[0])
     A("s_mov_b32 %%[plo], s%d" % PTR)
     A("s_mov_b32 %%[phi], s%d" % (PTR + 1))
+    A("s_mov_b32 %%[pend], s%d" % PEND)
     return L
 
 
