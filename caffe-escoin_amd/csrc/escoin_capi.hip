@@ -56,10 +56,11 @@ static void free_device(escoin_plan *p) {
   if (p->d_taps) (void)hipFree(p->d_taps);
   if (p->d_vals) (void)hipFree(p->d_vals);
   if (p->d_stream) (void)hipFree(p->d_stream);
-  if (p->d_stream_ptr) (void)hipFree(p->d_stream_ptr);
+  if (p->d_unit_hdr) (void)hipFree(p->d_unit_hdr);
+  p->d_unit_hdr = nullptr;
   if (p->d_dense_w) (void)hipFree(p->d_dense_w);
   p->d_dense_w = nullptr;
-  p->d_rowptr = p->d_taps = p->d_stream_ptr = nullptr;
+  p->d_rowptr = p->d_taps = nullptr;
   p->d_vals = nullptr;
   p->d_stream = nullptr;
   p->device_bytes = 0;
@@ -129,8 +130,10 @@ static int upload(escoin_plan *p, hipStream_t stream) {
   if (want_tiled) {
     if (!tiled_supported(g))
       return fail(ESCOIN_EINVAL, "tiled kernel requested for a geometry it does not support");
-    int rc = tiled_build(p, stream);
+    int rc = tiled_build(p, stream);   // leaves tiled.enabled false when the stream does not fit LDS
     if (rc != ESCOIN_OK) return rc;
+    if (!p->tiled.enabled && p->kernel_choice == ESCOIN_KERNEL_TILED)
+      return fail(ESCOIN_EINVAL, "tiled kernel requested but its weight stream does not fit the LDS budget");
   }
   p->kernel_name = p->tiled.enabled ? tiled_kernel_name(p) : generic_kernel_name(g.d.fuse_relu != 0);
   p->aligned = true;

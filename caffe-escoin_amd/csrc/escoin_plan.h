@@ -47,6 +47,8 @@ struct TiledConfig {
   int n_icb = 0;       // blocks per group
   int slots = 0;       // records per row group in the weight stream
   size_t lds_bytes = 0;
+  int lds_budget = 0;  // plane-buffer budget the tiling was chosen with
+  int stage_bytes = 0; // LDS bytes of one wave's weight-stream staging area
 };
 
 }  // namespace escoin
@@ -72,8 +74,8 @@ struct escoin_plan {
 
   // device arrays for the tiled kernel
   escoin::TiledConfig tiled;
-  unsigned *d_stream = nullptr;   // row-grouped weight stream
-  int *d_stream_ptr = nullptr;    // per (oc-wave-group, ic-block) offsets into d_stream
+  unsigned *d_stream = nullptr;   // unit bodies of the weight stream (stream_builder.h)
+  unsigned *d_unit_hdr = nullptr; // 8 dwords per (conv group, oc group, ic block)
   size_t stream_words = 0;
 
   // dense fallback (fp32 MFMA implicit GEMM)

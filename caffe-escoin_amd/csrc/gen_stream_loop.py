@@ -229,6 +229,147 @@ def generate_init():
     return L
 
 
+# ------------------------------------------------------------------------------------------
+# Stream format 2 (stream_builder.h): the unit's body is staged in LDS with the planes; a group's
+# quad(s) [meta, v0, v1, v2] ([meta2, v3, v4, v5]) arrive as broadcast ds_read_b128 one group
+# ahead and the values feed v_pk_fma_f32 as VGPR pairs (op_sel picks the half): no v_readlane,
+# no vector-memory wait inside the loop.  Per group the vector ALU sees one v_readfirstlane
+# (meta), the address adds and the FMAs.
+#
+#   v32,v33   LDS addresses of the next group's input quads      v34  LDS address of the
+#   v[36:51]  input quads, two phases (as above)                       current group's payload
+#   v[52:55], v[56:59]  first payload quad, two phases            v[60:63] second payload quad
+# Operands: %[h0] lead meta of group 0, %[h1]..%[h6] = END_6..END_1, %[lbA]/%[lbB], %[sbase] LDS
+# byte address of the wave's staging area.
+# ------------------------------------------------------------------------------------------
+P0 = [52, 56]
+P1 = 60
+VP = 34
+META, META2, HDR2 = 34, 35, 36
+IX0 = [38, 39]
+MAX_SLOTS2 = 6
+
+
+def bfe(dst, src, off, width):
+    return "s_bfe_u32 s%d, s%d, 0x%x" % (dst, src, (width << 16) | off)
+
+
+def pk4v(L, r, p):
+    """Record r of the current group: value = half of a payload VGPR pair."""
+    if "nopk" in ABL:
+        return
+    base = P0[p] if r < 3 else P1
+    q = r % 3
+    pair, sel = (base, 1) if q == 0 else ((base + 2, 0) if q == 1 else (base + 2, 1))
+    for (acc, x) in ((ACC_A, XA[p]), (ACC_A + 2, XA[p] + 2), (ACC_B, XB[p]), (ACC_B + 2, XB[p] + 2)):
+        L.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], v[%d:%d], v[%d:%d] op_sel:[%d,0,0] op_sel_hi:[%d,1,1]"
+                 % (acc, acc + 1, pair, pair + 1, x, x + 1, acc, acc + 1, sel, sel))
+
+
+def prefetch2(L, p_next, stride, band):
+    """LDS reads of the next group: its two input quads (row offset in s[HDR2]) and its first
+    payload quad.  Runs with GPR index 0."""
+    A = L.append
+    if "noxp" in ABL:
+        if stride:
+            A("ds_read_b128 v[%d:%d], v%d offset:%d" % (P0[p_next], P0[p_next] + 3, VP, stride))
+            A("v_add_u32 v%d, %d, v%d" % (VP, stride, VP))
+        else:
+            A("ds_read_b128 v[%d:%d], v%d" % (P0[p_next], P0[p_next] + 3, VP))
+        return
+    A("v_add_u32 v%d, s%d, %%[lbA]" % (VA, HDR2))
+    if band:
+        A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
+        A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[p_next], XB[p_next] + 3, VA))
+    else:
+        A("v_add_u32 v%d, s%d, %%[lbB]" % (VB, HDR2))
+        A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
+        A("ds_read_b128 v[%d:%d], v%d" % (XB[p_next], XB[p_next] + 3, VB))
+    if stride:
+        A("ds_read_b128 v[%d:%d], v%d offset:%d" % (P0[p_next], P0[p_next] + 3, VP, stride))
+        A("v_add_u32 v%d, %d, v%d" % (VP, stride, VP))
+    else:
+        A("ds_read_b128 v[%d:%d], v%d" % (P0[p_next], P0[p_next] + 3, VP))
+
+
+def body2(L, n, p, band):
+    """Group k (cursor c, phase p).  On entry: X(k), P0(k) were requested at the top of group k-1;
+    s[HDR2] = row offset of group k+1, s[IX0[p]] = accumulator of this group's record 0."""
+    A = L.append
+    c, nx = CUR[p], CUR[1 - p]
+    stride = 32 if n > 3 else 16
+    A("ESC2_L%d_%d_%%=:" % (n, p))
+    A("s_set_gpr_idx_idx 0")
+    if n > 3:
+        A("ds_read_b128 v[%d:%d], v%d offset:16" % (P1, P1 + 3, VP))
+    prefetch2(L, 1 - p, stride, band)          # group k+1: a whole group of FMAs to land in
+    A("s_add_u32 s%d, s%d, 1" % (nx, c))
+    if "noxp" in ABL:
+        A("s_waitcnt lgkmcnt(%d)" % (2 if n > 3 else 1))
+    else:
+        A("s_waitcnt lgkmcnt(%d)" % (4 if n > 3 else 3))   # X(k), P0(k) landed
+    A("s_set_gpr_idx_idx s%d" % IX0[p])
+    pk4v(L, 0, p)
+    A("v_readfirstlane_b32 s%d, v%d" % (META, P0[p]))
+    A(bfe(HDR2, META, 0, 12))                  # row offset of group k+2
+    A("s_lshl_b32 s%d, s%d, 4" % (HDR2, HDR2))
+    A(bfe(IX0[1 - p], META, 12, 5))
+    A("s_lshl_b32 s%d, s%d, 2" % (IX0[1 - p], IX0[1 - p]))
+    for r in range(1, n):
+        t = IXT[r % 2]
+        if r < 3:
+            A(bfe(t, META, 12 + 5 * r, 5))
+            A("s_lshl_b32 s%d, s%d, 2" % (t, t))
+        if r == 3:
+            A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))   # the second quad (older than the prefetches) landed
+            A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
+        if r >= 3:
+            A(bfe(t, META2, 5 * (r - 3), 5))
+            A("s_lshl_b32 s%d, s%d, 2" % (t, t))
+        A("s_set_gpr_idx_idx s%d" % t)
+        pk4v(L, r, p)
+    A("s_cmp_eq_u32 s%d, s%d" % (nx, END0 + n))
+    A("s_cbranch_scc1 ESC2_E%d_%d_%%=" % (n - 1, 1 - p))
+    if p == 1:
+        A("s_branch ESC2_L%d_0_%%=" % n)
+
+
+def generate2(band):
+    L = []
+    A = L.append
+    A("s_waitcnt lgkmcnt(0)")
+    for n in range(1, MAX_SLOTS2 + 1):
+        A("s_mov_b32 s%d, %%[h%d]" % (END0 + n, 7 - n))
+    A("s_cmp_eq_u32 s%d, 0" % (END0 + 1))
+    A("s_cbranch_scc1 ESC2_X_%=")
+    A("s_mov_b32 s%d, 0" % CUR[0])
+    A("s_mov_b32 s%d, %%[h0]" % META)
+    A(bfe(HDR2, META, 0, 12))                  # group 0
+    A("s_lshl_b32 s%d, s%d, 4" % (HDR2, HDR2))
+    A(bfe(IX0[0], META, 12, 5))
+    A("s_lshl_b32 s%d, s%d, 2" % (IX0[0], IX0[0]))
+    A("v_mov_b32 v%d, %%[sbase]" % VP)
+    prefetch2(L, 0, 0, band)
+    A(bfe(HDR2, META, 17, 12))                 # group 1
+    A("s_lshl_b32 s%d, s%d, 4" % (HDR2, HDR2))
+    A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % IX0[0])
+    A("s_branch ESC2_E%d_0_%%=" % MAX_SLOTS2)
+    for n in range(MAX_SLOTS2, 0, -1):
+        for p in (0, 1):
+            A("ESC2_E%d_%d_%%=:" % (n, p))
+            A("s_cmp_eq_u32 s%d, s%d" % (CUR[p], END0 + n))
+            A("s_cbranch_scc1 ESC2_E%d_%d_%%=" % (n - 1, p))
+            A("s_branch ESC2_L%d_%d_%%=" % (n, p))
+        body2(L, n, 0, band)
+        body2(L, n, 1, band)
+    A("ESC2_E0_0_%=:")
+    A("ESC2_E0_1_%=:")
+    A("s_set_gpr_idx_off")
+    A("ESC2_X_%=:")
+    A("s_waitcnt lgkmcnt(0)")
+    return L
+
+
 def clobbers():
     c = ["memory", "scc", "m0", "exec"]
     c += ["s%d" % i for i in range(32, 64)]
@@ -256,9 +397,13 @@ def main():
     for name in ("nopk", "noxp", "nop4", "vnop4"):
         ABL.add(name)
         emit_macro(out, "ESC_STREAM_LOOP_ASM_" + name.upper(), generate())
+        if name in ("nopk", "noxp"):
+            emit_macro(out, "ESC2_LOOP_ASM_" + name.upper(), generate2(False))
         ABL.discard(name)
     out.write("#endif\n")
     emit_macro(out, "ESC_STREAM_INIT_ASM", generate_init())
+    emit_macro(out, "ESC2_LOOP_ASM", generate2(False))
+    emit_macro(out, "ESC2_LOOP_ASM_BAND", generate2(True))
     out.write("#define ESC_STREAM_LOOP_CLOBBERS \\\n  ")
     out.write(", ".join('"%s"' % c for c in clobbers()))
     out.write("\n")

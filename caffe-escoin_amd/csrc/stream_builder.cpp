@@ -211,4 +211,88 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
   return ws;
 }
 
+
+WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
+                            const std::vector<std::vector<int>> &rowptr,
+                            const std::vector<std::vector<int>> &colidx,
+                            const std::vector<std::vector<float>> &values) {
+  WeightStream2 ws;
+  const size_t n_units = (size_t)g.group * t.n_ocg * t.n_icb;
+  ws.unit_hdr.assign(n_units * kUnitHdrDwords, 0u);
+  const int rows_per_blk = t.icb * g.KH;
+  std::vector<std::vector<Rec>> rows(rows_per_blk);   // records per (ic_local, kr); idx = quad
+  auto f2u = [](float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    return u;
+  };
+  for (int cg = 0; cg < g.group; ++cg)
+    for (int ocg = 0; ocg < t.n_ocg; ++ocg)
+      for (int blk = 0; blk < t.n_icb; ++blk) {
+        for (auto &r : rows) r.clear();
+        const int ic_lo = blk * t.icb, ic_hi = std::min(g.Cg, ic_lo + t.icb);
+        for (int gl = 0; gl < t.G; ++gl) {
+          const int m = ocg * t.G + gl;
+          if (m >= g.Mg) break;
+          for (int j = rowptr[cg][m]; j < rowptr[cg][m + 1]; ++j) {
+            const int col = colidx[cg][j];
+            const int kc = col % g.KW, kr = (col / g.KW) % g.KH, ic = col / (g.KW * g.KH);
+            if (ic < ic_lo || ic >= ic_hi) continue;
+            Rec rec;
+            rec.val = values[cg][j];
+            rec.idx = (uint8_t)(gl * g.KW + kc);
+            rows[(ic - ic_lo) * g.KH + kr].push_back(rec);
+          }
+        }
+        std::vector<Group> groups;
+        for (int r = 0; r < rows_per_blk; ++r) {
+          const std::vector<Rec> &rr = rows[r];
+          const int icl = r / g.KH, kr = r % g.KH;
+          const uint32_t off = (uint32_t)(((size_t)icl * t.plane_ch_floats + (size_t)kr * t.RS) * 4);
+          for (size_t b = 0; b < rr.size(); b += kMaxSlots2) {
+            Group gr;
+            gr.lds_off = off;
+            gr.recs.assign(rr.begin() + b, rr.begin() + std::min(rr.size(), b + kMaxSlots2));
+            groups.push_back(gr);
+          }
+        }
+        std::stable_sort(groups.begin(), groups.end(), [](const Group &a, const Group &b) {
+          return a.recs.size() > b.recs.size();
+        });
+        const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
+        uint32_t *hdr = &ws.unit_hdr[ui * kUnitHdrDwords];
+        const int tg = (int)groups.size();
+        auto row16 = [&](int k) -> uint32_t { return k < tg ? groups[k].lds_off / 16u : 0u; };
+        auto first = [&](int k) -> uint32_t { return k < tg ? (uint32_t)groups[k].recs[0].idx : 0u; };
+        hdr[0] = row16(0) | (first(0) << 12) | (row16(1) << 17);
+        for (int n = kMaxSlots2; n >= 1; --n) {
+          int cum = 0;
+          for (const Group &gr : groups) cum += ((int)gr.recs.size() >= n) ? 1 : 0;
+          hdr[1 + (kMaxSlots2 - n)] = (uint32_t)cum;
+        }
+        hdr[7] = (uint32_t)(ws.words.size() * 4);
+        const size_t body = ws.words.size();
+        for (int k = 0; k < tg; ++k) {
+          const Group &gr = groups[k];
+          const int n = (int)gr.recs.size();
+          uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          q[0] = row16(k + 2) | (first(k + 1) << 12);
+          if (n > 1) q[0] |= (uint32_t)gr.recs[1].idx << 17;
+          if (n > 2) q[0] |= (uint32_t)gr.recs[2].idx << 22;
+          for (int s = 0; s < n && s < 3; ++s) q[1 + s] = f2u(gr.recs[s].val);
+          for (int s = 3; s < n; ++s) {
+            q[4] |= (uint32_t)gr.recs[s].idx << (5 * (s - 3));
+            q[5 + (s - 3)] = f2u(gr.recs[s].val);
+          }
+          ws.words.insert(ws.words.end(), q, q + (n > 3 ? 8 : 4));
+          ws.n_records += n;
+        }
+        ws.n_groups += tg;
+        ws.max_body_bytes = std::max(ws.max_body_bytes, (int)((ws.words.size() - body) * 4));
+      }
+  // the staging copy of the last unit reads up to one staging area past its start
+  ws.words.resize(ws.words.size() + (size_t)stage_bytes_for(ws.max_body_bytes) / 4, 0u);
+  return ws;
+}
+
 }  // namespace escoin

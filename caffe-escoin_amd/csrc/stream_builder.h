@@ -89,5 +89,46 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
                           const std::vector<std::vector<int>> &colidx,
                           const std::vector<std::vector<float>> &values);
 
+// ---- stream format 2: staged in LDS with the planes, values read as broadcast quads ----------
+//
+// One unit per (conv group, oc-group, input-channel block) as above, but split in two parts:
+//   unit_hdr[8 * unit + ...]   (read with scalar loads, one s_load_dwordx8 per block and wave)
+//     [0]     what groups 0 and 1 need before any quad has been read: row offset / 16 of group 0
+//             (bits 0..11), accumulator quad of its record 0 (12..16), row offset / 16 of group 1
+//             (17..28)
+//     [1..6]  END_6, END_5, ..., END_1: END_n = number of groups with >= n records (the groups of
+//             a unit are sorted by record count, descending; END_1 = number of groups)
+//     [7]     byte offset of the unit's body in `words`
+//   body (copied into the wave's LDS staging area by LDS-DMA one block ahead)
+//     per group one quad [meta, v0, v1, v2]; groups with more than 3 records a second quad
+//     [meta2, v3, v4, v5]; the kernel reads them as broadcast ds_read_b128 and feeds the values to
+//     v_pk_fma_f32 straight from the VGPR pair (op_sel picks the half).
+//     meta  = (row offset of the group AFTER the next) / 16      bits 0..11
+//           | accumulator quad of record 0 of the NEXT group     bits 12..16
+//           | accumulator quad of this group's record 1, 2       bits 17..21, 22..26
+//     meta2 = accumulator quads of records 3, 4, 5              bits 0..4, 5..9, 10..14
+//     accumulator quad = g_local * KW + kc (VGPR offset / 4).
+// A group's row offset travels two groups ahead and its first accumulator one group ahead: the LDS
+// reads of group k+1's input quads are issued at the very top of group k (a whole group of FMA
+// work to land in) and nothing on the path to a group's first FMA waits for its own quad's meta.
+constexpr int kMaxSlots2 = 6;
+constexpr int kUnitHdrDwords = 8;
+
+struct WeightStream2 {
+  std::vector<uint32_t> words;      // bodies back to back, 16-byte aligned
+  std::vector<uint32_t> unit_hdr;   // [group][n_ocg][n_icb][8]
+  int max_body_bytes = 0;
+  long n_groups = 0, n_records = 0;
+};
+
+WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
+                            const std::vector<std::vector<int>> &rowptr,
+                            const std::vector<std::vector<int>> &colidx,
+                            const std::vector<std::vector<float>> &values);
+
+// Bytes of one wave's staging area for a stream whose largest body is max_body_bytes: the body is
+// copied in 1 KiB DMA steps and the loop prefetches one quad past the last group.
+inline int stage_bytes_for(int max_body_bytes) { return (max_body_bytes + 32 + 1023) / 1024 * 1024; }
+
 }  // namespace escoin
 #endif

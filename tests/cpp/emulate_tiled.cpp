@@ -24,7 +24,7 @@ static float frand() {
 
 struct Case { int N, C, H, W, M, KH, KW, ph, pw, group; float sparsity; int waves; int lds; };
 
-static int run(const Case &cs) {
+static int run(const Case &cs, int fmt) {
   ConvGeom g{cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, 0, 0, 0, 0};
   g.OH = cs.H + 2 * cs.ph - cs.KH + 1;
   g.OW = cs.W + 2 * cs.pw - cs.KW + 1;
@@ -49,7 +49,11 @@ static int run(const Case &cs) {
       rp[cg][m + 1] = (int)ci[cg].size();
     }
   }
-  WeightStream ws = build_stream(g, t, rp, ci, va);
+  WeightStream ws;
+  WeightStream2 ws2;
+  if (fmt == 1) ws = build_stream(g, t, rp, ci, va);
+  else ws2 = build_stream2(g, t, rp, ci, va);
+  if (fmt == 2 && stage_bytes_for(ws2.max_body_bytes) > 16384) { printf("staging area too large\n"); return 5; }
 
   // reference dense conv (double)
   std::vector<double> want((size_t)g.N * g.M * g.OH * g.OW, 0.0);
@@ -106,6 +110,54 @@ static int run(const Case &cs) {
             const int pw = wave % t.pix_waves, ow_ = wave / t.pix_waves;
             const int ocg = ocblk * t.oc_waves + ow_;
             if (ocg >= t.n_ocg) continue;
+            if (fmt == 2) {
+              // format 2: the unit's body sits in the wave's staging area; row offset and first
+              // accumulator of a group come from the previous group's meta word
+              const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
+              const uint32_t *hdr = &ws2.unit_hdr[ui * kUnitHdrDwords];
+              const uint32_t *body = &ws2.words[hdr[7] / 4];
+              uint32_t row_cur = hdr[0] & 0xFFF, ix0 = (hdr[0] >> 12) & 31, row_next = (hdr[0] >> 17) & 0xFFF;
+              size_t pos = 0;   // dword position in the body
+              uint32_t k2 = 0;
+              for (int n = kMaxSlots2; n >= 1; --n) {
+                const uint32_t end_n = hdr[1 + (kMaxSlots2 - n)];
+                while (k2 != end_n) {
+                  const uint32_t *q = body + pos;
+                  const uint32_t row_off = row_cur * 16;
+                  int idx[6];
+                  idx[0] = (int)ix0;
+                  idx[1] = (q[0] >> 17) & 31;
+                  idx[2] = (q[0] >> 22) & 31;
+                  if (n > 3) { idx[3] = q[4] & 31; idx[4] = (q[4] >> 5) & 31; idx[5] = (q[4] >> 10) & 31; }
+                  for (int lane = 0; lane < 64; ++lane)
+                    for (int tl = 0; tl < 2; ++tl) {
+                      const int fr = (pw * 2 + tl) * t.rows_per_slab + lane / t.S4;
+                      const int seg = fr / t.tr, yl = fr % t.tr, j = lane % t.S4;
+                      size_t base = ((size_t)seg * t.plane_rows + yl) * t.RS + 4 * j;
+                      if (seg >= t.nseg) base = 0;
+                      const size_t a = base + row_off / 4;
+                      float *A = &acc[((size_t)wave * 64 + lane) * kAccAll + tl * kAccRegsPerTile];
+                      for (int s = 0; s < n; ++s) {
+                        float v;
+                        std::memcpy(&v, &q[s < 3 ? 1 + s : 5 + (s - 3)], 4);
+                        if (4 * idx[s] + 3 >= kAccRegsPerTile) { printf("acc idx out of range\n"); return 3; }
+                        for (int e = 0; e < 4; ++e) {
+                          const float xv = (a + e < lds.size()) ? lds[a + e] : 0.f;
+                          A[4 * idx[s] + e] = std::fmaf(v, xv, A[4 * idx[s] + e]);
+                        }
+                      }
+                    }
+                  row_cur = row_next;
+                  row_next = q[0] & 0xFFF;
+                  ix0 = (q[0] >> 12) & 31;
+                  pos += n > 3 ? 8 : 4;
+                  ++k2;
+                }
+              }
+              if (row_cur != 0 || row_next != 0 || ix0 != 0) { printf("leads past the last group are not empty\n"); return 3; }
+              if ((int)(pos * 4) > ws2.max_body_bytes) { printf("body longer than max_body_bytes\n"); return 3; }
+              continue;
+            }
             // the wave's stream is continuous over the ic blocks: chunk indices are relative to
             // the first unit of (cg, ocg)
             const uint32_t *wstream = &ws.words[ws.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb]];
@@ -195,8 +247,10 @@ static int run(const Case &cs) {
   printf("N%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
          "groups=%ld recs=%ld recs/group=%.2f rel_err=%.2e\n",
          cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.S4, t.G,
-         t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes, ws.n_groups,
-         ws.n_records, ws.n_groups ? (double)ws.n_records / (double)ws.n_groups : 0.0, rel);
+         t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes,
+         fmt == 1 ? ws.n_groups : ws2.n_groups, fmt == 1 ? ws.n_records : ws2.n_records,
+         fmt == 1 ? (ws.n_groups ? (double)ws.n_records / (double)ws.n_groups : 0.0)
+                  : (ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0), rel);
   return rel <= 1e-5 ? 0 : 1;
 }
 
@@ -224,7 +278,10 @@ int main() {
       {3, 6, 13, 13, 10, 1, 1, 0, 0, 2, 0.7f, 8, 65536},    // pointwise 13x13 (169 = 13^2), groups
   };
   int bad = 0;
-  for (const Case &c : cases) bad += run(c) != 0;
+  for (int fmt = 1; fmt <= 2; ++fmt) {
+    printf("---- stream format %d ----\n", fmt);
+    for (const Case &c : cases) bad += run(c, fmt) != 0;
+  }
   printf(bad ? "FAILED %d case(s)\n" : "all cases OK\n", bad);
   return bad ? 1 : 0;
 }
