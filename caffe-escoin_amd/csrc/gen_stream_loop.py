@@ -267,7 +267,7 @@ def pk4v(L, r, p):
 
 
 def prefetch2(L, p_next, stride, band):
-    """LDS reads of the next group: its two input quads (row offset in s[HDR2]) and its first
+    """LDS reads of the next group: its two input quads (row offset / 32 in s[HDR2]) and its first
     payload quad.  Runs with GPR index 0."""
     A = L.append
     if "noxp" in ABL:
@@ -277,12 +277,12 @@ def prefetch2(L, p_next, stride, band):
         else:
             A("ds_read_b128 v[%d:%d], v%d" % (P0[p_next], P0[p_next] + 3, VP))
         return
-    A("v_add_u32 v%d, s%d, %%[lbA]" % (VA, HDR2))
+    A("v_lshl_add_u32 v%d, s%d, 5, %%[lbA]" % (VA, HDR2))
     if band:
         A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
         A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[p_next], XB[p_next] + 3, VA))
     else:
-        A("v_add_u32 v%d, s%d, %%[lbB]" % (VB, HDR2))
+        A("v_lshl_add_u32 v%d, s%d, 5, %%[lbB]" % (VB, HDR2))
         A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
         A("ds_read_b128 v[%d:%d], v%d" % (XB[p_next], XB[p_next] + 3, VB))
     if stride:
@@ -292,18 +292,28 @@ def prefetch2(L, p_next, stride, band):
         A("ds_read_b128 v[%d:%d], v%d" % (P0[p_next], P0[p_next] + 3, VP))
 
 
+CNT = 32                     # groups left in the current bucket after the current one
+
+
+def ix_field(dst, src, r):
+    """Accumulator VGPR offset of record r (r = 1, 2 from meta; 3..5 from meta2; 'n' = the next
+    group's record 0): one scalar op."""
+    off = {1: 7, 2: 0, 3: 0, 4: 7, 5: 14, "n": 14}[r]
+    if off == 0:
+        return "s_and_b32 s%d, s%d, 0x7f" % (dst, src)
+    return bfe(dst, src, off, 7)
+
+
 def body2(L, n, p, band):
-    """Group k (cursor c, phase p).  On entry: X(k), P0(k) were requested at the top of group k-1;
-    s[HDR2] = row offset of group k+1, s[IX0[p]] = accumulator of this group's record 0."""
+    """Group k (phase p).  On entry: X(k), P0(k) were requested at the top of group k-1;
+    s[HDR2] = row offset / 32 of group k+1, s[IX0[p]] = accumulator of this group's record 0."""
     A = L.append
-    c, nx = CUR[p], CUR[1 - p]
     stride = 32 if n > 3 else 16
     A("ESC2_L%d_%d_%%=:" % (n, p))
     A("s_set_gpr_idx_idx 0")
     if n > 3:
         A("ds_read_b128 v[%d:%d], v%d offset:16" % (P1, P1 + 3, VP))
     prefetch2(L, 1 - p, stride, band)          # group k+1: a whole group of FMAs to land in
-    A("s_add_u32 s%d, s%d, 1" % (nx, c))
     if "noxp" in ABL:
         A("s_waitcnt lgkmcnt(%d)" % (2 if n > 3 else 1))
     else:
@@ -311,27 +321,23 @@ def body2(L, n, p, band):
     A("s_set_gpr_idx_idx s%d" % IX0[p])
     pk4v(L, 0, p)
     A("v_readfirstlane_b32 s%d, v%d" % (META, P0[p]))
-    A(bfe(HDR2, META, 0, 12))                  # row offset of group k+2
-    A("s_lshl_b32 s%d, s%d, 4" % (HDR2, HDR2))
-    A(bfe(IX0[1 - p], META, 12, 5))
-    A("s_lshl_b32 s%d, s%d, 2" % (IX0[1 - p], IX0[1 - p]))
+    A("s_lshr_b32 s%d, s%d, 21" % (HDR2, META))          # row offset / 32 of group k+2
+    A(ix_field(IX0[1 - p], META, "n"))
     for r in range(1, n):
         t = IXT[r % 2]
-        if r < 3:
-            A(bfe(t, META, 12 + 5 * r, 5))
-            A("s_lshl_b32 s%d, s%d, 2" % (t, t))
         if r == 3:
             A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))   # the second quad (older than the prefetches) landed
             A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
-        if r >= 3:
-            A(bfe(t, META2, 5 * (r - 3), 5))
-            A("s_lshl_b32 s%d, s%d, 2" % (t, t))
+        A(ix_field(t, META if r < 3 else META2, r))
         A("s_set_gpr_idx_idx s%d" % t)
         pk4v(L, r, p)
-    A("s_cmp_eq_u32 s%d, s%d" % (nx, END0 + n))
-    A("s_cbranch_scc1 ESC2_E%d_%d_%%=" % (n - 1, 1 - p))
-    if p == 1:
-        A("s_branch ESC2_L%d_0_%%=" % n)
+    # s_add_u32 x, x, -1: SCC = carry = (x was not 0) = another group follows in this bucket
+    A("s_add_u32 s%d, s%d, -1" % (CNT, CNT))
+    if p == 0:
+        A("s_cbranch_scc0 ESC2_E%d_1_%%=" % (n - 1))     # falls through into phase 1
+    else:
+        A("s_cbranch_scc1 ESC2_L%d_0_%%=" % n)
+        A("s_branch ESC2_E%d_0_%%=" % (n - 1))
 
 
 def generate2(band):
@@ -340,25 +346,25 @@ def generate2(band):
     A("s_waitcnt lgkmcnt(0)")
     for n in range(1, MAX_SLOTS2 + 1):
         A("s_mov_b32 s%d, %%[h%d]" % (END0 + n, 7 - n))
+    A("s_mov_b32 s%d, 0" % (END0 + MAX_SLOTS2 + 1))
     A("s_cmp_eq_u32 s%d, 0" % (END0 + 1))
     A("s_cbranch_scc1 ESC2_X_%=")
-    A("s_mov_b32 s%d, 0" % CUR[0])
     A("s_mov_b32 s%d, %%[h0]" % META)
-    A(bfe(HDR2, META, 0, 12))                  # group 0
-    A("s_lshl_b32 s%d, s%d, 4" % (HDR2, HDR2))
-    A(bfe(IX0[0], META, 12, 5))
-    A("s_lshl_b32 s%d, s%d, 2" % (IX0[0], IX0[0]))
+    A("s_and_b32 s%d, s%d, 0x7ff" % (HDR2, META))        # group 0
+    A(ix_field(IX0[0], META, "n"))
     A("v_mov_b32 v%d, %%[sbase]" % VP)
     prefetch2(L, 0, 0, band)
-    A(bfe(HDR2, META, 17, 12))                 # group 1
-    A("s_lshl_b32 s%d, s%d, 4" % (HDR2, HDR2))
+    A("s_lshr_b32 s%d, s%d, 21" % (HDR2, META))          # group 1
     A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % IX0[0])
     A("s_branch ESC2_E%d_0_%%=" % MAX_SLOTS2)
     for n in range(MAX_SLOTS2, 0, -1):
         for p in (0, 1):
+            # bucket n: groups [END_(n+1), END_n)
             A("ESC2_E%d_%d_%%=:" % (n, p))
-            A("s_cmp_eq_u32 s%d, s%d" % (CUR[p], END0 + n))
+            A("s_sub_u32 s%d, s%d, s%d" % (CNT, END0 + n, END0 + n + 1))
+            A("s_cmp_eq_u32 s%d, 0" % CNT)
             A("s_cbranch_scc1 ESC2_E%d_%d_%%=" % (n - 1, p))
+            A("s_sub_u32 s%d, s%d, 1" % (CNT, CNT))
             A("s_branch ESC2_L%d_%d_%%=" % (n, p))
         body2(L, n, 0, band)
         body2(L, n, 1, band)

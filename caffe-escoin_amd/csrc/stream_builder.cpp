@@ -24,7 +24,7 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
   if (waves_per_wg != 1 && waves_per_wg != 2 && waves_per_wg != 4 && waves_per_wg != 8) return t;
   t.KW = g.KW;
   t.KH = g.KH;
-  t.S4 = next_pow2((g.W + 3) / 4);
+  t.S4 = std::max(2, next_pow2((g.W + 3) / 4));   // rows are >= 32 bytes (the stream stores offsets / 32)
   t.RS = 4 * t.S4;
   t.rows_per_slab = 64 / t.S4;
   // Output channels per wave.  The accumulator file bounds it (KW=1:24 2:12 3:8 4:6 5:4); within
@@ -262,9 +262,9 @@ WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
         const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
         uint32_t *hdr = &ws.unit_hdr[ui * kUnitHdrDwords];
         const int tg = (int)groups.size();
-        auto row16 = [&](int k) -> uint32_t { return k < tg ? groups[k].lds_off / 16u : 0u; };
-        auto first = [&](int k) -> uint32_t { return k < tg ? (uint32_t)groups[k].recs[0].idx : 0u; };
-        hdr[0] = row16(0) | (first(0) << 12) | (row16(1) << 17);
+        auto row32 = [&](int k) -> uint32_t { return k < tg ? groups[k].lds_off / 32u : 0u; };
+        auto first = [&](int k) -> uint32_t { return k < tg ? 4u * groups[k].recs[0].idx : 0u; };
+        hdr[0] = row32(0) | (first(0) << 14) | (row32(1) << 21);
         for (int n = kMaxSlots2; n >= 1; --n) {
           int cum = 0;
           for (const Group &gr : groups) cum += ((int)gr.recs.size() >= n) ? 1 : 0;
@@ -276,12 +276,12 @@ WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
           const Group &gr = groups[k];
           const int n = (int)gr.recs.size();
           uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          q[0] = row16(k + 2) | (first(k + 1) << 12);
-          if (n > 1) q[0] |= (uint32_t)gr.recs[1].idx << 17;
-          if (n > 2) q[0] |= (uint32_t)gr.recs[2].idx << 22;
+          q[0] = (row32(k + 2) << 21) | (first(k + 1) << 14);
+          if (n > 1) q[0] |= 4u * gr.recs[1].idx << 7;
+          if (n > 2) q[0] |= 4u * gr.recs[2].idx;
           for (int s = 0; s < n && s < 3; ++s) q[1 + s] = f2u(gr.recs[s].val);
           for (int s = 3; s < n; ++s) {
-            q[4] |= (uint32_t)gr.recs[s].idx << (5 * (s - 3));
+            q[4] |= 4u * gr.recs[s].idx << (7 * (s - 3));
             q[5 + (s - 3)] = f2u(gr.recs[s].val);
           }
           ws.words.insert(ws.words.end(), q, q + (n > 3 ? 8 : 4));

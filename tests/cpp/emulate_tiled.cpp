@@ -116,19 +116,19 @@ static int run(const Case &cs, int fmt) {
               const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
               const uint32_t *hdr = &ws2.unit_hdr[ui * kUnitHdrDwords];
               const uint32_t *body = &ws2.words[hdr[7] / 4];
-              uint32_t row_cur = hdr[0] & 0xFFF, ix0 = (hdr[0] >> 12) & 31, row_next = (hdr[0] >> 17) & 0xFFF;
+              uint32_t row_cur = hdr[0] & 0x7FF, ix0 = (hdr[0] >> 14) & 127, row_next = hdr[0] >> 21;
               size_t pos = 0;   // dword position in the body
               uint32_t k2 = 0;
               for (int n = kMaxSlots2; n >= 1; --n) {
                 const uint32_t end_n = hdr[1 + (kMaxSlots2 - n)];
                 while (k2 != end_n) {
                   const uint32_t *q = body + pos;
-                  const uint32_t row_off = row_cur * 16;
+                  const uint32_t row_off = row_cur * 32;
                   int idx[6];
                   idx[0] = (int)ix0;
-                  idx[1] = (q[0] >> 17) & 31;
-                  idx[2] = (q[0] >> 22) & 31;
-                  if (n > 3) { idx[3] = q[4] & 31; idx[4] = (q[4] >> 5) & 31; idx[5] = (q[4] >> 10) & 31; }
+                  idx[1] = (q[0] >> 7) & 127;
+                  idx[2] = q[0] & 127;
+                  if (n > 3) { idx[3] = q[4] & 127; idx[4] = (q[4] >> 7) & 127; idx[5] = (q[4] >> 14) & 127; }
                   for (int lane = 0; lane < 64; ++lane)
                     for (int tl = 0; tl < 2; ++tl) {
                       const int fr = (pw * 2 + tl) * t.rows_per_slab + lane / t.S4;
@@ -140,16 +140,16 @@ static int run(const Case &cs, int fmt) {
                       for (int s = 0; s < n; ++s) {
                         float v;
                         std::memcpy(&v, &q[s < 3 ? 1 + s : 5 + (s - 3)], 4);
-                        if (4 * idx[s] + 3 >= kAccRegsPerTile) { printf("acc idx out of range\n"); return 3; }
+                        if (idx[s] % 4 != 0 || idx[s] + 3 >= kAccRegsPerTile) { printf("acc idx out of range\n"); return 3; }
                         for (int e = 0; e < 4; ++e) {
                           const float xv = (a + e < lds.size()) ? lds[a + e] : 0.f;
-                          A[4 * idx[s] + e] = std::fmaf(v, xv, A[4 * idx[s] + e]);
+                          A[idx[s] + e] = std::fmaf(v, xv, A[idx[s] + e]);
                         }
                       }
                     }
                   row_cur = row_next;
-                  row_next = q[0] & 0xFFF;
-                  ix0 = (q[0] >> 12) & 31;
+                  row_next = q[0] >> 21;
+                  ix0 = (q[0] >> 14) & 127;
                   pos += n > 3 ? 8 : 4;
                   ++k2;
                 }
