@@ -7,247 +7,50 @@ Design notes (all measured on MI355X, tools/probes/):
     near 125) and >= 2 waves per SIMD;
   * the accumulator a nonzero updates is data dependent -> GPR-index mode (M0) with VDST and
     VSRC2 relative; works with VOP3P;
-  * scalar loads cannot stream the weights (about two 64-byte lines in flight per wave, ~750
-    cycles per line): the stream comes in through the VECTOR memory path instead, 64 chunks of
-    48 bytes held lane-distributed in 12 VGPRs (lane l = chunk l mod 64), refilled half a window
-    (32 lanes, EXEC-masked) at a time 32 chunks ahead of use, and single dwords are broadcast
-    with v_readlane_b32;
+  * at 2 waves/SIMD every instruction a wave issues costs it an issue slot, scalar ones included
+    (s_nop is the exception that misled an earlier version): the loop is built to need as few
+    instructions per group as the data flow allows;
+  * scalar loads cannot stream the weights (about two 64-byte lines in flight per wave) and
+    v_readlane broadcasts out of a lane-distributed VGPR window cost 7.5 ns each: the unit's body
+    is staged in LDS with the planes (LDS-DMA, one block ahead); a group's quad(s)
+    [meta, v0, v1, v2] ([meta2, v3, v4, v5]) arrive as broadcast ds_read_b128 one group ahead and
+    the values feed v_pk_fma_f32 as VGPR pairs (op_sel picks the half): no vector-memory wait
+    inside the loop, one v_readfirstlane (meta) per group;
   * a lane owns two pixel quads (tiles A and B) so one record = 4 v_pk_fma_f32.
 
 Register contract with sconv_tiled.hip (C++ compiled with amdgpu_num_vgpr(NV): the compiler
 never touches v[NV..255]):
-    v32,v33          LDS addresses of the next group's quads (tile A, tile B)
-    v[36:51]         input quads: phase p -> A: v[36+8p..], B: v[40+8p..]
-    v[52:63]         stream window (dword d of the chunks in v[52+d])
-    v[64:159]        tile-A accumulators, v[160:255] tile-B accumulators (same index + 96)
-    s[32:59]         scratch owned by the asm (cursor, bucket ends, values, ...)
-Operands: %[k] chunk cursor (in/out), %[plo]/%[phi] address of the next half window to request
-(in/out), %[pend] 1 while a half-window request may be in flight (in/out; the kernel clears it
-after a full vmcnt drain), %[lbA]/%[lbB] the lane's LDS byte addresses of its two quads (plane row 0, channel
-0), %[voff] (lane & 31) * 48.
+    v32,v33   LDS addresses of the next group's input quads      v34  LDS address of the
+    v[36:51]  input quads: phase p -> A: v[36+8p..], B: v[40+8p..]      current group's payload
+    v[52:55], v[56:59]  first payload quad, two phases            v[60:63] second payload quad
+    v[64:159] tile-A accumulators, v[160:255] tile-B accumulators (same index + 96)
+    s[32:45]  scratch owned by the asm
+Operands: %[h0] lead word of the unit, %[h1]..%[h6] = END_6..END_1 (stream_builder.h),
+%[lbA]/%[lbB] the lane's LDS byte addresses of its two quads (plane row 0, channel 0),
+%[sbase] LDS byte address of the wave's staging area.
 
     python gen_stream_loop.py > stream_loop_asm.inc
 """
 import sys
 
 NV = 32
-VA, VB = 32, 33
+VA, VB, VP = 32, 33, 34
 XA = [36, 44]
 XB = [40, 48]
-SW = 52                      # stream window registers
-ACC_A, ACC_B = 64, 160
-NACC_TILE = 96
-CUR = [32, 33]               # chunk cursor, alternating by phase
-STOP = 34
-HDR = 35
-IX, IX2 = 36, 37
-VAL = [38, 40]               # SGPR pairs (value, junk)
-END0 = 41                    # END_n in s[END0 + n], n = 1..8
-UEND = 50
-TMP = 51
-PTR = 54                     # s[54:55]
-EXS = 56                     # s[56:57] saved exec
-IXT = [58, 59]               # alternating shifted-index temporaries
-PEND = 52                    # 1: a half-window request may still be in flight
-_label = [0]
-MAX_SLOTS = 8
-ABL = set()                  # generator switches: 'band' + timing-only ablations (see main())
-HALF_BYTES = 32 * 48
-
-
-def refill(L, cur):
-    """Cursor `cur` (SGPR number) sits on a multiple of 32: wait for its half window and
-    request the next one into the lanes of the half that was just consumed."""
-    A = L.append
-    # The half holding chunk `cur` was requested 32 chunks ago.  vmcnt completes in order, so
-    # waiting for it also waits for everything issued since -- in particular the next block's
-    # LDS-DMA, which the workgroup issues at every block start.  The kernel drains vmcnt at each
-    # block start anyway and clears PEND there: only a request younger than that drain needs a wait.
-    _label[0] += 1
-    A("s_cmp_eq_u32 s%d, 0" % PEND)
-    A("s_cbranch_scc1 ESC_RW%d_%%=" % _label[0])
-    A("s_waitcnt vmcnt(0)")
-    A("ESC_RW%d_%%=:" % _label[0])
-    A("s_bitcmp1_b32 s%d, 5" % cur)
-    A("s_cselect_b32 exec_lo, -1, 0")
-    A("s_cselect_b32 exec_hi, 0, -1")
-    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d]" % (SW, SW + 3, PTR, PTR + 1))
-    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d] offset:16" % (SW + 4, SW + 7, PTR, PTR + 1))
-    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d] offset:32" % (SW + 8, SW + 11, PTR, PTR + 1))
-    A("s_mov_b64 exec, s[%d:%d]" % (EXS, EXS + 1))
-    A("s_add_u32 s%d, s%d, %d" % (PTR, PTR, HALF_BYTES))
-    A("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1))
-    A("s_mov_b32 s%d, 1" % PEND)
-
-
-def x_prefetch(L, cur, xset):
-    """Issue the LDS reads of group `cur`'s two quads into X set `xset` (index 0: no relocation)."""
-    A = L.append
-    A("v_readlane_b32 s%d, v%d, s%d" % (HDR, SW, cur))
-    if "noxp" in ABL:
-        return
-    A("s_set_gpr_idx_idx 0")
-    A("v_add_u32 v%d, s%d, %%[lbA]" % (VA, HDR))
-    if "band" in ABL:
-        # band mode: tile B is the next 64-quad slab of the same plane, 1 KiB further
-        A("ds_read_b128 v[%d:%d], v%d" % (XA[xset], XA[xset] + 3, VA))
-        A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[xset], XB[xset] + 3, VA))
-        return
-    A("v_add_u32 v%d, s%d, %%[lbB]" % (VB, HDR))
-    A("ds_read_b128 v[%d:%d], v%d" % (XA[xset], XA[xset] + 3, VA))
-    A("ds_read_b128 v[%d:%d], v%d" % (XB[xset], XB[xset] + 3, VB))
-
-
-def pk4(L, val, p):
-    A = L.append
-    if "nopk" in ABL:
-        return
-    for (acc, x) in ((ACC_A, XA[p]), (ACC_A + 2, XA[p] + 2), (ACC_B, XB[p]), (ACC_B + 2, XB[p] + 2)):
-        A("v_pk_fma_f32 v[%d:%d], s[%d:%d], v[%d:%d], v[%d:%d] op_sel_hi:[0,1,1]"
-          % (acc, acc + 1, val, val + 1, x, x + 1, acc, acc + 1))
-
-
-def entry(L, n, p):
-    """Bucket entry / stop handler: bucket exhausted -> next bucket; window crossing -> refill and
-    redo the X prefetch; then recompute the stop and fall into the loop."""
-    A = L.append
-    c = CUR[p]
-    A("ESC_E%d_%d_%%=:" % (n, p))
-    A("s_cmp_eq_u32 s%d, s%d" % (c, END0 + n))
-    A("s_cbranch_scc1 ESC_E%d_%d_%%=" % (n - 1, p))
-    A("s_and_b32 s%d, s%d, 31" % (TMP, c))
-    A("s_cmp_lg_u32 s%d, 0" % TMP)
-    A("s_cbranch_scc1 ESC_S%d_%d_%%=" % (n, p))
-    refill(L, c)
-    x_prefetch(L, c, p)
-    A("ESC_S%d_%d_%%=:" % (n, p))
-    A("s_or_b32 s%d, s%d, 31" % (TMP, c))
-    A("s_add_u32 s%d, s%d, 1" % (TMP, TMP))
-    A("s_min_u32 s%d, s%d, s%d" % (STOP, TMP, END0 + n))
-
-
-def loop_body(L, n, p):
-    A = L.append
-    c, nx = CUR[p], CUR[1 - p]
-    A("ESC_L%d_%d_%%=:" % (n, p))
-    A("v_readlane_b32 s%d, v%d, s%d" % (IX, SW + 1, c))
-    A("v_readlane_b32 s%d, v%d, s%d" % (VAL[0], SW + 3, c))
-    A("s_add_u32 s%d, s%d, 1" % (nx, c))
-    if n > 4:
-        A("v_readlane_b32 s%d, v%d, s%d" % (IX2, SW + 2, c))
-    if n > 1:
-        A("v_readlane_b32 s%d, v%d, s%d" % (VAL[1], SW + 4, c))
-    A("s_waitcnt lgkmcnt(0)")
-
-    def ixreg(r):
-        if r == 0:
-            return IX
-        if r == 4:
-            return IX2
-        return IXT[r % 2]
-
-    for r in range(n):
-        A("s_set_gpr_idx_idx s%d" % ixreg(r))
-        if r + 1 < n and (r + 1) % 4 != 0:
-            # next record's index byte, computed while this record's FMAs issue
-            A("s_lshr_b32 s%d, s%d, %d" % (ixreg(r + 1), IX if r + 1 < 4 else IX2, 8 * ((r + 1) % 4)))
-        pk4(L, VAL[r % 2], p)
-        if r + 2 < n:
-            A("v_readlane_b32 s%d, v%d, s%d" % (VAL[r % 2], SW + 3 + r + 2, c))
-        if r == 0:
-            x_prefetch(L, nx, 1 - p)
-    if "nop4" in ABL:
-        A("s_nop 0"); A("s_nop 0"); A("s_nop 0"); A("s_nop 0")
-    if "vnop4" in ABL:
-        A("v_nop"); A("v_nop"); A("v_nop"); A("v_nop")
-    A("s_cmp_eq_u32 s%d, s%d" % (nx, STOP))
-    A("s_cbranch_scc1 ESC_E%d_%d_%%=" % (n, 1 - p))
-    if p == 1:
-        A("s_branch ESC_L%d_0_%%=" % n)
-
-
-def generate():
-    L = []
-    _label[0] = 0
-    A = L.append
-    c0 = CUR[0]
-    A("s_mov_b64 s[%d:%d], exec" % (EXS, EXS + 1))
-    A("s_mov_b32 s%d, %%[k]" % c0)
-    A("s_mov_b32 s%d, %%[plo]" % PTR)
-    A("s_mov_b32 s%d, %%[phi]" % (PTR + 1))
-    A("s_mov_b32 s%d, %%[pend]" % PEND)
-    # unit header chunk (may sit on a window crossing)
-    A("s_and_b32 s%d, s%d, 31" % (TMP, c0))
-    A("s_cmp_lg_u32 s%d, 0" % TMP)
-    A("s_cbranch_scc1 ESC_H_%=")
-    refill(L, c0)
-    A("ESC_H_%=:")
-    A("v_readlane_b32 s%d, v%d, s%d" % (UEND, SW, c0))
-    for n in range(1, MAX_SLOTS + 1):
-        A("v_readlane_b32 s%d, v%d, s%d" % (END0 + n, SW + n, c0))
-    A("s_add_u32 s%d, s%d, 1" % (c0, c0))
-    A("s_nop 3")                                   # SALU write -> v_readlane lane select
-    A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % c0)   # index set before every use
-    x_prefetch(L, c0, 0)
-    for n in range(MAX_SLOTS, 0, -1):
-        # the entries for both phases, then the two loop bodies
-        entry(L, n, 0)
-        A("s_branch ESC_L%d_0_%%=" % n)
-        entry(L, n, 1)
-        A("s_branch ESC_L%d_1_%%=" % n)
-        loop_body(L, n, 0)
-        loop_body(L, n, 1)
-    A("ESC_E0_1_%=:")
-    A("s_mov_b32 s%d, s%d" % (CUR[0], CUR[1]))
-    A("ESC_E0_0_%=:")
-    A("s_set_gpr_idx_off")
-    A("s_waitcnt lgkmcnt(0)")
-    A("s_mov_b32 %%[k], s%d" % CUR[0])
-    A("s_mov_b32 %%[plo], s%d" % PTR)
-    A("s_mov_b32 %%[phi], s%d" % (PTR + 1))
-    A("s_mov_b32 %%[pend], s%d" % PEND)
-    return L
-
-
-def generate_init():
-    """Requests half window 0 (chunks 0..31 of the wave's stream) into lanes 0..31."""
-    L = []
-    A = L.append
-    A("s_mov_b64 s[%d:%d], exec" % (EXS, EXS + 1))
-    A("s_mov_b32 s%d, %%[plo]" % PTR)
-    A("s_mov_b32 s%d, %%[phi]" % (PTR + 1))
-    A("s_mov_b32 exec_lo, -1")
-    A("s_mov_b32 exec_hi, 0")
-    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d]" % (SW, SW + 3, PTR, PTR + 1))
-    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d] offset:16" % (SW + 4, SW + 7, PTR, PTR + 1))
-    A("global_load_dwordx4 v[%d:%d], %%[voff], s[%d:%d] offset:32" % (SW + 8, SW + 11, PTR, PTR + 1))
-    A("s_mov_b64 exec, s[%d:%d]" % (EXS, EXS + 1))
-    A("s_add_u32 s%d, s%d, %d" % (PTR, PTR, HALF_BYTES))
-    A("s_addc_u32 s%d, s%d, 0" % (PTR + 1, PTR + 1))
-    A("s_mov_b32 %%[plo], s%d" % PTR)
-    A("s_mov_b32 %%[phi], s%d" % (PTR + 1))
-    return L
-
-
-# ------------------------------------------------------------------------------------------
-# Stream format 2 (stream_builder.h): the unit's body is staged in LDS with the planes; a group's
-# quad(s) [meta, v0, v1, v2] ([meta2, v3, v4, v5]) arrive as broadcast ds_read_b128 one group
-# ahead and the values feed v_pk_fma_f32 as VGPR pairs (op_sel picks the half): no v_readlane,
-# no vector-memory wait inside the loop.  Per group the vector ALU sees one v_readfirstlane
-# (meta), the address adds and the FMAs.
-#
-#   v32,v33   LDS addresses of the next group's input quads      v34  LDS address of the
-#   v[36:51]  input quads, two phases (as above)                       current group's payload
-#   v[52:55], v[56:59]  first payload quad, two phases            v[60:63] second payload quad
-# Operands: %[h0] lead meta of group 0, %[h1]..%[h6] = END_6..END_1, %[lbA]/%[lbB], %[sbase] LDS
-# byte address of the wave's staging area.
-# ------------------------------------------------------------------------------------------
 P0 = [52, 56]
 P1 = 60
-VP = 34
-META, META2, HDR2 = 34, 35, 36
-IX0 = [38, 39]
+ACC_A, ACC_B = 64, 160
+NACC_TILE = 96
+CNT = 32                     # groups left in the current bucket after the current one
+META_P = [33, 34]            # meta of the current group, by phase: the NEXT group reads its
+                             # record-0 accumulator straight out of bits 0..7
+META2 = 35
+HDR2 = 36                    # row offset / 32 of the group after the current one
+IXT = [37, 38]               # alternating accumulator-index temporaries
+END0 = 38                    # END_n in s[END0 + n], n = 1..6; s[END0 + 7] = 0
+SGPR_LAST = 45
 MAX_SLOTS2 = 6
+ABL = set()                  # timing-only ablations (see main())
 
 
 def bfe(dst, src, off, width):
@@ -292,24 +95,18 @@ def prefetch2(L, p_next, stride, band):
         A("ds_read_b128 v[%d:%d], v%d" % (P0[p_next], P0[p_next] + 3, VP))
 
 
-CNT = 32                     # groups left in the current bucket after the current one
-
-
-def ix_field(dst, src, r):
-    """Accumulator VGPR offset of record r (r = 1, 2 from meta; 3..5 from meta2; 'n' = the next
-    group's record 0): one scalar op."""
-    off = {1: 7, 2: 0, 3: 0, 4: 7, 5: 14, "n": 14}[r]
-    if off == 0:
-        return "s_and_b32 s%d, s%d, 0x7f" % (dst, src)
-    return bfe(dst, src, off, 7)
-
-
 def body2(L, n, p, band):
     """Group k (phase p).  On entry: X(k), P0(k) were requested at the top of group k-1;
-    s[HDR2] = row offset / 32 of group k+1, s[IX0[p]] = accumulator of this group's record 0."""
+    s[HDR2] = row offset / 32 of group k+1, s[META_P[1-p]] bits 0..7 = accumulator of this group's
+    record 0 (left there by group k-1, or by the prologue)."""
     A = L.append
     stride = 32 if n > 3 else 16
+    meta = META_P[p]
     A("ESC2_L%d_%d_%%=:" % (n, p))
+    # The two waves of a SIMD are arbitrated oldest-first: left alone, the younger one runs ~25 %
+    # slower all kernel long and every block waits for it.  Alternating priority by group parity
+    # lets whichever wave is behind win its even groups.
+    A("s_setprio %d" % (1 - p))
     A("s_set_gpr_idx_idx 0")
     if n > 3:
         A("ds_read_b128 v[%d:%d], v%d offset:16" % (P1, P1 + 3, VP))
@@ -318,18 +115,23 @@ def body2(L, n, p, band):
         A("s_waitcnt lgkmcnt(%d)" % (2 if n > 3 else 1))
     else:
         A("s_waitcnt lgkmcnt(%d)" % (4 if n > 3 else 3))   # X(k), P0(k) landed
-    A("s_set_gpr_idx_idx s%d" % IX0[p])
+    A("s_set_gpr_idx_idx s%d" % META_P[1 - p])
     pk4v(L, 0, p)
-    A("v_readfirstlane_b32 s%d, v%d" % (META, P0[p]))
-    A("s_lshr_b32 s%d, s%d, 21" % (HDR2, META))          # row offset / 32 of group k+2
-    A(ix_field(IX0[1 - p], META, "n"))
+    A("v_readfirstlane_b32 s%d, v%d" % (meta, P0[p]))
+    A("s_lshr_b32 s%d, s%d, 21" % (HDR2, meta))          # row offset / 32 of group k+2
     for r in range(1, n):
         t = IXT[r % 2]
         if r == 3:
             A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))   # the second quad (older than the prefetches) landed
             A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
-        A(ix_field(t, META if r < 3 else META2, r))
-        A("s_set_gpr_idx_idx s%d" % t)
+            A("s_set_gpr_idx_idx s%d" % META2)           # record 3: bits 0..7 of meta2 as they are
+        else:
+            src, sh = (meta, 7 * r) if r < 3 else (META2, 7 * (r - 3))
+            if sh == 14 and r < 3:
+                A(bfe(t, src, 14, 7))                      # bit 21 above it belongs to the row offset
+            else:
+                A("s_lshr_b32 s%d, s%d, %d" % (t, src, sh))
+            A("s_set_gpr_idx_idx s%d" % t)
         pk4v(L, r, p)
     # s_add_u32 x, x, -1: SCC = carry = (x was not 0) = another group follows in this bucket
     A("s_add_u32 s%d, s%d, -1" % (CNT, CNT))
@@ -349,13 +151,12 @@ def generate2(band):
     A("s_mov_b32 s%d, 0" % (END0 + MAX_SLOTS2 + 1))
     A("s_cmp_eq_u32 s%d, 0" % (END0 + 1))
     A("s_cbranch_scc1 ESC2_X_%=")
-    A("s_mov_b32 s%d, %%[h0]" % META)
-    A("s_and_b32 s%d, s%d, 0x7ff" % (HDR2, META))        # group 0
-    A(ix_field(IX0[0], META, "n"))
+    A("s_mov_b32 s%d, %%[h0]" % META_P[1])                # plays the meta of "group -1"
+    A(bfe(HDR2, META_P[1], 8, 11))                       # group 0
     A("v_mov_b32 v%d, %%[sbase]" % VP)
     prefetch2(L, 0, 0, band)
-    A("s_lshr_b32 s%d, s%d, 21" % (HDR2, META))          # group 1
-    A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % IX0[0])
+    A("s_lshr_b32 s%d, s%d, 21" % (HDR2, META_P[1]))     # group 1
+    A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % META_P[1])
     A("s_branch ESC2_E%d_0_%%=" % MAX_SLOTS2)
     for n in range(MAX_SLOTS2, 0, -1):
         for p in (0, 1):
@@ -370,6 +171,7 @@ def generate2(band):
         body2(L, n, 1, band)
     A("ESC2_E0_0_%=:")
     A("ESC2_E0_1_%=:")
+    A("s_setprio 0")
     A("s_set_gpr_idx_off")
     A("ESC2_X_%=:")
     A("s_waitcnt lgkmcnt(0)")
@@ -377,8 +179,8 @@ def generate2(band):
 
 
 def clobbers():
-    c = ["memory", "scc", "m0", "exec"]
-    c += ["s%d" % i for i in range(32, 64)]
+    c = ["memory", "scc", "m0"]
+    c += ["s%d" % i for i in range(32, SGPR_LAST + 1)]
     c += ["v%d" % i for i in range(VA, 256)]
     return c
 
@@ -394,22 +196,15 @@ def main():
     out = sys.stdout
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
-    emit_macro(out, "ESC_STREAM_LOOP_ASM", generate())
-    ABL.add("band")
-    emit_macro(out, "ESC_STREAM_LOOP_ASM_BAND", generate())
-    ABL.discard("band")
-    # timing-only ablations (wrong results), compiled in with -DESCOIN_ABLATIONS
-    out.write("#ifdef ESCOIN_ABLATIONS\n")
-    for name in ("nopk", "noxp", "nop4", "vnop4"):
-        ABL.add(name)
-        emit_macro(out, "ESC_STREAM_LOOP_ASM_" + name.upper(), generate())
-        if name in ("nopk", "noxp"):
-            emit_macro(out, "ESC2_LOOP_ASM_" + name.upper(), generate2(False))
-        ABL.discard(name)
-    out.write("#endif\n")
-    emit_macro(out, "ESC_STREAM_INIT_ASM", generate_init())
     emit_macro(out, "ESC2_LOOP_ASM", generate2(False))
     emit_macro(out, "ESC2_LOOP_ASM_BAND", generate2(True))
+    # timing-only ablations (wrong results), compiled in with -DESCOIN_ABLATIONS
+    out.write("#ifdef ESCOIN_ABLATIONS\n")
+    for name in ("nopk", "noxp"):
+        ABL.add(name)
+        emit_macro(out, "ESC2_LOOP_ASM_" + name.upper(), generate2(False))
+        ABL.discard(name)
+    out.write("#endif\n")
     out.write("#define ESC_STREAM_LOOP_CLOBBERS \\\n  ")
     out.write(", ".join('"%s"' % c for c in clobbers()))
     out.write("\n")

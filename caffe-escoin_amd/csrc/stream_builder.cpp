@@ -264,7 +264,7 @@ WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
         const int tg = (int)groups.size();
         auto row32 = [&](int k) -> uint32_t { return k < tg ? groups[k].lds_off / 32u : 0u; };
         auto first = [&](int k) -> uint32_t { return k < tg ? 4u * groups[k].recs[0].idx : 0u; };
-        hdr[0] = row32(0) | (first(0) << 14) | (row32(1) << 21);
+        hdr[0] = first(0) | (row32(0) << 8) | (row32(1) << 21);
         for (int n = kMaxSlots2; n >= 1; --n) {
           int cum = 0;
           for (const Group &gr : groups) cum += ((int)gr.recs.size() >= n) ? 1 : 0;
@@ -276,9 +276,9 @@ WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
           const Group &gr = groups[k];
           const int n = (int)gr.recs.size();
           uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          q[0] = (row32(k + 2) << 21) | (first(k + 1) << 14);
+          q[0] = (row32(k + 2) << 21) | first(k + 1);
           if (n > 1) q[0] |= 4u * gr.recs[1].idx << 7;
-          if (n > 2) q[0] |= 4u * gr.recs[2].idx;
+          if (n > 2) q[0] |= 4u * gr.recs[2].idx << 14;
           for (int s = 0; s < n && s < 3; ++s) q[1 + s] = f2u(gr.recs[s].val);
           for (int s = 3; s < n; ++s) {
             q[4] |= 4u * gr.recs[s].idx << (7 * (s - 3));

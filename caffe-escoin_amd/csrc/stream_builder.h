@@ -93,9 +93,8 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
 //
 // One unit per (conv group, oc-group, input-channel block) as above, but split in two parts:
 //   unit_hdr[8 * unit + ...]   (read with scalar loads, one s_load_dwordx8 per block and wave)
-//     [0]     what groups 0 and 1 need before any quad has been read: row offset / 32 of group 0
-//             (bits 0..10), VGPR offset of the accumulator of its record 0 (14..20), row
-//             offset / 32 of group 1 (21..31)
+//     [0]     what groups 0 and 1 need before any quad has been read: accumulator of group 0's
+//             record 0 (bits 0..6), row offset / 32 of group 0 (8..18) and of group 1 (21..31)
 //     [1..6]  END_6, END_5, ..., END_1: END_n = number of groups with >= n records (the groups of
 //             a unit are sorted by record count, descending; END_1 = number of groups)
 //     [7]     byte offset of the unit's body in `words`
@@ -104,12 +103,13 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
 //     [meta2, v3, v4, v5]; the kernel reads them as broadcast ds_read_b128 and feeds the values to
 //     v_pk_fma_f32 straight from the VGPR pair (op_sel picks the half).
 //     meta  = (row offset of the group AFTER the next) / 32      bits 21..31
-//           | accumulator of record 0 of the NEXT group          bits 14..20
-//           | accumulator of this group's record 1, 2            bits 7..13, 0..6
+//           | accumulator of this group's record 2, 1            bits 14..20, 7..13
+//           | accumulator of record 0 of the NEXT group          bits 0..6
 //     meta2 = accumulators of records 3, 4, 5                    bits 0..6, 7..13, 14..20
 //     accumulator = 4 * (g_local * KW + kc): the VGPR offset GPR-index mode adds, ready for
-//     s_set_gpr_idx_idx after ONE scalar op (shift or bit-field extract) -- every instruction a
-//     wave issues costs it an issue slot at 2 waves/SIMD, scalar ones included.
+//     s_set_gpr_idx_idx (which reads bits 0..7 of its operand; bit 7 is always a zero low bit of
+//     the neighbouring field) directly or after ONE scalar shift -- every instruction a wave
+//     issues costs it an issue slot at 2 waves/SIMD, scalar ones included.
 // A group's row offset travels two groups ahead and its first accumulator one group ahead: the LDS
 // reads of group k+1's input quads are issued at the very top of group k (a whole group of FMA
 // work to land in) and nothing on the path to a group's first FMA waits for its own quad's meta.

@@ -116,7 +116,8 @@ static int run(const Case &cs, int fmt) {
               const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
               const uint32_t *hdr = &ws2.unit_hdr[ui * kUnitHdrDwords];
               const uint32_t *body = &ws2.words[hdr[7] / 4];
-              uint32_t row_cur = hdr[0] & 0x7FF, ix0 = (hdr[0] >> 14) & 127, row_next = hdr[0] >> 21;
+              if (hdr[0] & 0x80) { printf("bit 7 of the lead word is not clear\n"); return 3; }
+              uint32_t row_cur = (hdr[0] >> 8) & 0x7FF, ix0 = hdr[0] & 127, row_next = hdr[0] >> 21;
               size_t pos = 0;   // dword position in the body
               uint32_t k2 = 0;
               for (int n = kMaxSlots2; n >= 1; --n) {
@@ -127,7 +128,7 @@ static int run(const Case &cs, int fmt) {
                   int idx[6];
                   idx[0] = (int)ix0;
                   idx[1] = (q[0] >> 7) & 127;
-                  idx[2] = q[0] & 127;
+                  idx[2] = (q[0] >> 14) & 127;
                   if (n > 3) { idx[3] = q[4] & 127; idx[4] = (q[4] >> 7) & 127; idx[5] = (q[4] >> 14) & 127; }
                   for (int lane = 0; lane < 64; ++lane)
                     for (int tl = 0; tl < 2; ++tl) {
@@ -149,7 +150,7 @@ static int run(const Case &cs, int fmt) {
                     }
                   row_cur = row_next;
                   row_next = q[0] >> 21;
-                  ix0 = (q[0] >> 14) & 127;
+                  ix0 = q[0] & 127;
                   pos += n > 3 ? 8 : 4;
                   ++k2;
                 }
