@@ -130,93 +130,10 @@ struct Group {
 }  // namespace
 
 WeightStream build_stream(const ConvGeom &g, const Tiling &t,
-                          const std::vector<std::vector<int>> &rowptr,
-                          const std::vector<std::vector<int>> &colidx,
-                          const std::vector<std::vector<float>> &values) {
-  WeightStream ws;
-  const size_t n_units = (size_t)g.group * t.n_ocg * t.n_icb;
-  ws.unit_off.assign(n_units, 0);
-  ws.unit_chunks.assign(n_units, 0);
-  const int rows_per_blk = t.icb * g.KH;
-  std::vector<std::vector<Rec>> rows(rows_per_blk);   // records per (ic_local, kr)
-  for (int cg = 0; cg < g.group; ++cg) {
-    for (int ocg = 0; ocg < t.n_ocg; ++ocg) {
-      // chunk indices are relative to the start of this (cg, ocg) wave-stream: the kernel keeps
-      // one running chunk cursor across the ic blocks
-      const size_t stream_start = ws.words.size();
-      for (int blk = 0; blk < t.n_icb; ++blk) {
-        for (auto &r : rows) r.clear();
-        const int ic_lo = blk * t.icb, ic_hi = std::min(g.Cg, ic_lo + t.icb);
-        for (int gl = 0; gl < t.G; ++gl) {
-          const int m = ocg * t.G + gl;
-          if (m >= g.Mg) break;
-          for (int j = rowptr[cg][m]; j < rowptr[cg][m + 1]; ++j) {
-            const int col = colidx[cg][j];
-            const int kc = col % g.KW, kr = (col / g.KW) % g.KH, ic = col / (g.KW * g.KH);
-            if (ic < ic_lo || ic >= ic_hi) continue;
-            Rec rec;
-            rec.val = values[cg][j];
-            rec.idx = (uint8_t)(4 * (gl * g.KW + kc));
-            rows[(ic - ic_lo) * g.KH + kr].push_back(rec);
-          }
-        }
-        std::vector<Group> groups;
-        for (int r = 0; r < rows_per_blk; ++r) {
-          const std::vector<Rec> &rr = rows[r];
-          const int icl = r / g.KH, kr = r % g.KH;
-          const uint32_t off = (uint32_t)(((size_t)icl * t.plane_ch_floats + (size_t)kr * t.RS) * 4);
-          for (size_t b = 0; b < rr.size(); b += kMaxSlots) {
-            Group gr;
-            gr.lds_off = off;
-            gr.recs.assign(rr.begin() + b, rr.begin() + std::min(rr.size(), b + kMaxSlots));
-            groups.push_back(gr);
-          }
-        }
-        std::stable_sort(groups.begin(), groups.end(), [](const Group &a, const Group &b) {
-          return a.recs.size() > b.recs.size();
-        });
-        const size_t unit = ws.words.size();
-        const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
-        ws.unit_off[ui] = (int32_t)unit;
-        const int tg = (int)groups.size();
-        ws.unit_chunks[ui] = tg + 1;
-        ws.max_unit_chunks = std::max(ws.max_unit_chunks, tg + 1);
-        ws.words.resize(unit + (size_t)(tg + 1) * kChunkDwords, 0u);
-        const uint32_t hdr_idx = (uint32_t)((unit - stream_start) / kChunkDwords);
-        uint32_t *hdr = &ws.words[unit];
-        hdr[0] = hdr_idx + 1 + (uint32_t)tg;
-        for (int n = 1; n <= kMaxSlots; ++n) {
-          int cum = 0;
-          for (const Group &gr : groups) cum += ((int)gr.recs.size() >= n) ? 1 : 0;
-          hdr[n] = hdr_idx + 1 + (uint32_t)cum;
-        }
-        for (int k = 0; k < tg; ++k) {
-          uint32_t *c = &ws.words[unit + (size_t)(k + 1) * kChunkDwords];
-          const Group &gr = groups[k];
-          const int n = (int)gr.recs.size();
-          c[0] = gr.lds_off;
-          c[11] = (uint32_t)n;
-          for (int s = 0; s < n; ++s) {
-            c[1 + s / 4] |= (uint32_t)gr.recs[s].idx << (8 * (s % 4));
-            std::memcpy(&c[3 + s], &gr.recs[s].val, 4);
-          }
-          ws.n_records += n;
-        }
-        ws.n_groups += tg;
-      }
-    }
-  }
-  // the kernel prefetches up to two half-windows (64 chunks) past the cursor
-  ws.words.resize(ws.words.size() + (size_t)(kWindowChunks + 32) * kChunkDwords, 0u);
-  return ws;
-}
-
-
-WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
                             const std::vector<std::vector<int>> &rowptr,
                             const std::vector<std::vector<int>> &colidx,
                             const std::vector<std::vector<float>> &values) {
-  WeightStream2 ws;
+  WeightStream ws;
   const size_t n_units = (size_t)g.group * t.n_ocg * t.n_icb;
   ws.unit_hdr.assign(n_units * kUnitHdrDwords, 0u);
   const int rows_per_blk = t.icb * g.KH;
@@ -249,10 +166,10 @@ WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
           const std::vector<Rec> &rr = rows[r];
           const int icl = r / g.KH, kr = r % g.KH;
           const uint32_t off = (uint32_t)(((size_t)icl * t.plane_ch_floats + (size_t)kr * t.RS) * 4);
-          for (size_t b = 0; b < rr.size(); b += kMaxSlots2) {
+          for (size_t b = 0; b < rr.size(); b += kMaxSlots) {
             Group gr;
             gr.lds_off = off;
-            gr.recs.assign(rr.begin() + b, rr.begin() + std::min(rr.size(), b + kMaxSlots2));
+            gr.recs.assign(rr.begin() + b, rr.begin() + std::min(rr.size(), b + kMaxSlots));
             groups.push_back(gr);
           }
         }
@@ -265,10 +182,10 @@ WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
         auto row32 = [&](int k) -> uint32_t { return k < tg ? groups[k].lds_off / 32u : 0u; };
         auto first = [&](int k) -> uint32_t { return k < tg ? 4u * groups[k].recs[0].idx : 0u; };
         hdr[0] = first(0) | (row32(0) << 8) | (row32(1) << 21);
-        for (int n = kMaxSlots2; n >= 1; --n) {
+        for (int n = kMaxSlots; n >= 1; --n) {
           int cum = 0;
           for (const Group &gr : groups) cum += ((int)gr.recs.size() >= n) ? 1 : 0;
-          hdr[1 + (kMaxSlots2 - n)] = (uint32_t)cum;
+          hdr[1 + (kMaxSlots - n)] = (uint32_t)cum;
         }
         hdr[7] = (uint32_t)(ws.words.size() * 4);
         const size_t body = ws.words.size();

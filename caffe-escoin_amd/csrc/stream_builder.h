@@ -12,19 +12,8 @@
 // kernel-column shift kc is NOT applied to the input: by linearity a separate accumulator
 // class is kept per kc and the classes are shifted and summed once in the epilogue.
 //
-// Weight stream: one "unit" per (conv group, oc-group of G channels, input-channel block), a
-// sequence of 48-byte chunks (12 dwords).  The kernel stages a unit in LDS and keeps 64
-// consecutive chunks lane-distributed in 12 VGPRs (lane l = chunk l of the window), reading
-// single dwords out with v_readlane.
-//   chunk 0           header: [0] = Tg + 1 (index one past the last group chunk),
-//                             [n] (n = 1..8) = END_n = 1 + #groups with >= n records
-//   chunk 1..Tg       one group each = the records of one input row:
-//                       [0]      LDS byte offset of the row (ic_local*plane_ch_bytes + kr*RS*4)
-//                       [1],[2]  accumulator indices, one byte per record (records 0-3, 4-7):
-//                                4*(g_local*KW + kc) = VGPR offset of the tile-A accumulator quad
-//                       [3+r]    value of record r (fp32 bits), r < n <= 8
-//                       [11]     n
-// Groups are sorted by n descending so the kernel runs one unrolled loop per record count.
+// Weight stream: one "unit" per (conv group, oc-group of G channels, input-channel block); its
+// layout is described at WeightStream below.
 #ifndef ESCOIN_STREAM_BUILDER_H_
 #define ESCOIN_STREAM_BUILDER_H_
 
@@ -33,11 +22,8 @@
 
 namespace escoin {
 
-constexpr int kChunkDwords = 12;
-constexpr int kMaxSlots = 8;          // records per group
 constexpr int kTilesPerLane = 2;      // quads owned by a lane
 constexpr int kAccRegsPerTile = 96;   // accumulator VGPRs per tile (192 in all)
-constexpr int kWindowChunks = 64;     // chunks held lane-distributed in VGPRs
 
 struct ConvGeom {
   int N, C, H, W, M, KH, KW, pad_h, pad_w, group;
@@ -75,23 +61,9 @@ struct Tiling {
 // g.N fills the chip).
 Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu = 256);
 
-struct WeightStream {
-  std::vector<uint32_t> words;     // all units back to back
-  std::vector<int32_t> unit_off;   // [group][n_ocg][n_icb] -> dword offset of the unit header
-  std::vector<int32_t> unit_chunks;// [group][n_ocg][n_icb] -> chunks in the unit (Tg + 1)
-  int max_unit_chunks = 0;
-  long n_groups = 0, n_records = 0;
-};
-
-// rowptr/colidx/values: per conv group CSR with UNSTRETCHED columns ic*KH*KW + kr*KW + kc.
-WeightStream build_stream(const ConvGeom &g, const Tiling &t,
-                          const std::vector<std::vector<int>> &rowptr,
-                          const std::vector<std::vector<int>> &colidx,
-                          const std::vector<std::vector<float>> &values);
-
-// ---- stream format 2: staged in LDS with the planes, values read as broadcast quads ----------
+// ---- the weight stream: staged in LDS with the planes, values read as broadcast quads ---------
 //
-// One unit per (conv group, oc-group, input-channel block) as above, but split in two parts:
+// One unit per (conv group, oc-group, input-channel block), in two parts:
 //   unit_hdr[8 * unit + ...]   (read with scalar loads, one s_load_dwordx8 per block and wave)
 //     [0]     what groups 0 and 1 need before any quad has been read: accumulator of group 0's
 //             record 0 (bits 0..6), row offset / 32 of group 0 (8..18) and of group 1 (21..31)
@@ -113,17 +85,17 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
 // A group's row offset travels two groups ahead and its first accumulator one group ahead: the LDS
 // reads of group k+1's input quads are issued at the very top of group k (a whole group of FMA
 // work to land in) and nothing on the path to a group's first FMA waits for its own quad's meta.
-constexpr int kMaxSlots2 = 6;
+constexpr int kMaxSlots = 6;
 constexpr int kUnitHdrDwords = 8;
 
-struct WeightStream2 {
+struct WeightStream {
   std::vector<uint32_t> words;      // bodies back to back, 16-byte aligned
   std::vector<uint32_t> unit_hdr;   // [group][n_ocg][n_icb][8]
   int max_body_bytes = 0;
   long n_groups = 0, n_records = 0;
 };
 
-WeightStream2 build_stream2(const ConvGeom &g, const Tiling &t,
+WeightStream build_stream(const ConvGeom &g, const Tiling &t,
                             const std::vector<std::vector<int>> &rowptr,
                             const std::vector<std::vector<int>> &colidx,
                             const std::vector<std::vector<float>> &values);

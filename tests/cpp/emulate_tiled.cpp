@@ -2,7 +2,8 @@
 //
 // Builds the tiling + weight stream with the PRODUCT's stream builder (csrc/stream_builder.cpp)
 // and then walks it exactly the way sconv_tiled.hip does -- LDS planes, lane -> quad mapping,
-// bucket walk driven by the END_n markers, dst-relative accumulator classes, shift-and-sum
+// bucket walk driven by the END_n counts, leads handed on by the previous groups' meta words,
+// dst-relative accumulator classes, shift-and-sum
 // epilogue -- and compares against a plain dense convolution.  Lets the stream format and all
 // index arithmetic be validated without a GPU.  Not part of the product; not the oracle.
 #include <cmath>
@@ -24,7 +25,7 @@ static float frand() {
 
 struct Case { int N, C, H, W, M, KH, KW, ph, pw, group; float sparsity; int waves; int lds; };
 
-static int run(const Case &cs, int fmt) {
+static int run(const Case &cs) {
   ConvGeom g{cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, 0, 0, 0, 0};
   g.OH = cs.H + 2 * cs.ph - cs.KH + 1;
   g.OW = cs.W + 2 * cs.pw - cs.KW + 1;
@@ -49,11 +50,8 @@ static int run(const Case &cs, int fmt) {
       rp[cg][m + 1] = (int)ci[cg].size();
     }
   }
-  WeightStream ws;
-  WeightStream2 ws2;
-  if (fmt == 1) ws = build_stream(g, t, rp, ci, va);
-  else ws2 = build_stream2(g, t, rp, ci, va);
-  if (fmt == 2 && stage_bytes_for(ws2.max_body_bytes) > 16384) { printf("staging area too large\n"); return 5; }
+  WeightStream ws2 = build_stream(g, t, rp, ci, va);
+  if (stage_bytes_for(ws2.max_body_bytes) > 16384) { printf("staging area too large\n"); return 5; }
 
   // reference dense conv (double)
   std::vector<double> want((size_t)g.N * g.M * g.OH * g.OW, 0.0);
@@ -84,7 +82,6 @@ static int run(const Case &cs, int fmt) {
       for (int ocblk = 0; ocblk < t.n_ocblk; ++ocblk) {
         // per-wave accumulators: [wave][lane][192]
         std::vector<float> acc((size_t)t.waves * 64 * kAccAll, 0.f);
-        std::vector<uint32_t> cursor(t.waves, 0u);   // running chunk cursor per wave
         for (int blk = 0; blk < t.n_icb; ++blk) {
           // ---- fill ----
           std::fill(lds.begin(), lds.end(), 0.f);
@@ -110,7 +107,7 @@ static int run(const Case &cs, int fmt) {
             const int pw = wave % t.pix_waves, ow_ = wave / t.pix_waves;
             const int ocg = ocblk * t.oc_waves + ow_;
             if (ocg >= t.n_ocg) continue;
-            if (fmt == 2) {
+            {
               // format 2: the unit's body sits in the wave's staging area; row offset and first
               // accumulator of a group come from the previous group's meta word
               const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
@@ -120,8 +117,8 @@ static int run(const Case &cs, int fmt) {
               uint32_t row_cur = (hdr[0] >> 8) & 0x7FF, ix0 = hdr[0] & 127, row_next = hdr[0] >> 21;
               size_t pos = 0;   // dword position in the body
               uint32_t k2 = 0;
-              for (int n = kMaxSlots2; n >= 1; --n) {
-                const uint32_t end_n = hdr[1 + (kMaxSlots2 - n)];
+              for (int n = kMaxSlots; n >= 1; --n) {
+                const uint32_t end_n = hdr[1 + (kMaxSlots - n)];
                 while (k2 != end_n) {
                   const uint32_t *q = body + pos;
                   const uint32_t row_off = row_cur * 32;
@@ -157,46 +154,7 @@ static int run(const Case &cs, int fmt) {
               }
               if (row_cur != 0 || row_next != 0 || ix0 != 0) { printf("leads past the last group are not empty\n"); return 3; }
               if ((int)(pos * 4) > ws2.max_body_bytes) { printf("body longer than max_body_bytes\n"); return 3; }
-              continue;
             }
-            // the wave's stream is continuous over the ic blocks: chunk indices are relative to
-            // the first unit of (cg, ocg)
-            const uint32_t *wstream = &ws.words[ws.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb]];
-            uint32_t &k = cursor[wave];
-            const uint32_t *hdr = wstream + (size_t)k * kChunkDwords;
-            if (&ws.words[ws.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk]] != hdr) {
-              printf("cursor does not sit on the unit header\n"); return 3;
-            }
-            const uint32_t uend = hdr[0];
-            ++k;
-            for (int n = kMaxSlots; n >= 1; --n) {
-              while (k != hdr[n]) {
-                const uint32_t *c = wstream + (size_t)k * kChunkDwords;
-                if ((int)c[11] != n) { printf("bucket order broken\n"); return 3; }
-                for (int lane = 0; lane < 64; ++lane) {
-                  for (int tl = 0; tl < 2; ++tl) {
-                    const int fr = (pw * 2 + tl) * t.rows_per_slab + lane / t.S4;
-                    const int seg = fr / t.tr, yl = fr % t.tr, j = lane % t.S4;
-                    size_t base = ((size_t)seg * t.plane_rows + yl) * t.RS + 4 * j;
-                    if (seg >= t.nseg) base = 0;     // idle lanes read a valid but meaningless address
-                    const size_t a = base + c[0] / 4;
-                    float *A = &acc[((size_t)wave * 64 + lane) * kAccAll + tl * kAccRegsPerTile];
-                    for (int s = 0; s < n; ++s) {
-                      float v;
-                      std::memcpy(&v, &c[3 + s], 4);
-                      const int idx = (c[1 + s / 4] >> (8 * (s % 4))) & 0xFF;
-                      if (idx + 3 >= kAccRegsPerTile) { printf("acc idx out of range\n"); return 3; }
-                      for (int e = 0; e < 4; ++e) {
-                        const float xv = (a + e < lds.size()) ? lds[a + e] : 0.f;
-                        A[idx + e] = std::fmaf(v, xv, A[idx + e]);
-                      }
-                    }
-                  }
-                }
-                ++k;
-              }
-            }
-            if (k != uend) { printf("walked to %u, unit ends at %u\n", k, uend); return 3; }
           }
         }
         // ---- epilogue ----
@@ -249,9 +207,7 @@ static int run(const Case &cs, int fmt) {
          "groups=%ld recs=%ld recs/group=%.2f rel_err=%.2e\n",
          cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.S4, t.G,
          t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes,
-         fmt == 1 ? ws.n_groups : ws2.n_groups, fmt == 1 ? ws.n_records : ws2.n_records,
-         fmt == 1 ? (ws.n_groups ? (double)ws.n_records / (double)ws.n_groups : 0.0)
-                  : (ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0), rel);
+         ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, rel);
   return rel <= 1e-5 ? 0 : 1;
 }
 
@@ -279,10 +235,7 @@ int main() {
       {3, 6, 13, 13, 10, 1, 1, 0, 0, 2, 0.7f, 8, 65536},    // pointwise 13x13 (169 = 13^2), groups
   };
   int bad = 0;
-  for (int fmt = 1; fmt <= 2; ++fmt) {
-    printf("---- stream format %d ----\n", fmt);
-    for (const Case &c : cases) bad += run(c, fmt) != 0;
-  }
+  for (const Case &c : cases) bad += run(c) != 0;
   printf(bad ? "FAILED %d case(s)\n" : "all cases OK\n", bad);
   return bad ? 1 : 0;
 }
