@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ESCOIN_LIB") or os.path.join(_HERE, "libescoin_hip.so")
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED, KERNEL_DENSE = 0, 1, 2, 3
-CONV_MODE_SCONV, CONV_MODE_SCONV_PAR = 2, 3
+CONV_MODE_LOWERED_SPARSE, CONV_MODE_SCONV, CONV_MODE_SCONV_PAR = 1, 2, 3
 
 # every symbol include/escoin.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
@@ -31,7 +31,7 @@ API_SYMBOLS = [
     "escoin_weight_align", "escoin_plan_set_csr", "escoin_plan_nnz", "escoin_plan_get_csr",
     "escoin_plan_workspace_bytes", "escoin_plan_kernel_name", "escoin_forward",
     "escoin_gpu_sconv", "escoin_gpu_stretch", "escoin_copy_input_data",
-    "escoin_gpu_sparse_dense2csr",
+    "escoin_gpu_sparse_dense2csr", "escoin_gpu_sparse_csrmm",
 ]
 
 
@@ -110,6 +110,8 @@ def lib():
     L.escoin_copy_input_data.argtypes = [vp, vp] + [ip] * 5 + [vp]
     L.escoin_gpu_sparse_dense2csr.restype = ip
     L.escoin_gpu_sparse_dense2csr.argtypes = [ip, ip, vp, vp, vp, vp, vp, C.POINTER(ip), vp]
+    L.escoin_gpu_sparse_csrmm.restype = ip
+    L.escoin_gpu_sparse_csrmm.argtypes = [ip, ip, ip, ip, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp]
     _lib = L
     return L
 

@@ -58,6 +58,9 @@ static void free_device(escoin_plan *p) {
   if (p->d_stream) (void)hipFree(p->d_stream);
   if (p->d_unit_hdr) (void)hipFree(p->d_unit_hdr);
   p->d_unit_hdr = nullptr;
+  if (p->d_col) (void)hipFree(p->d_col);
+  p->d_col = nullptr;
+  p->col_bytes = 0;
   if (p->d_dense_w) (void)hipFree(p->d_dense_w);
   p->d_dense_w = nullptr;
   p->d_rowptr = p->d_taps = nullptr;
@@ -201,9 +204,10 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
       return fail(ESCOIN_EINVAL, "unknown kernel id");
     p->kernel_choice = value;
   } else if (!strcmp(key, "conv_mode")) {
-    if (value != ESCOIN_CONV_MODE_SCONV && value != ESCOIN_CONV_MODE_SCONV_PAR)
-      return fail(ESCOIN_EINVAL,
-                  "only conv_mode SCONV (2) and SCONV_PAR (3) are served by this library");
+    if (value != ESCOIN_CONV_MODE_SCONV && value != ESCOIN_CONV_MODE_SCONV_PAR &&
+        value != ESCOIN_CONV_MODE_LOWERED_SPARSE)
+      return fail(ESCOIN_EINVAL, "conv_mode must be SCONV (2), SCONV_PAR (3) or the LOWERED_SPARSE (1) "
+                                 "comparator; LOWERED_GEMM (0) is the kernel option ESCOIN_KERNEL_DENSE");
     p->conv_mode = value;
   } else if (!strcmp(key, "dense_gate")) {
     p->dense_gate = value != 0;
@@ -313,6 +317,8 @@ int escoin_plan_get_csr(const escoin_plan *p, int *rowptr, int *colidx, float *v
 size_t escoin_plan_workspace_bytes(const escoin_plan *p) { return p ? p->device_bytes : 0; }
 
 const char *escoin_plan_kernel_name(const escoin_plan *p) {
+  if (p && p->aligned && p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && !p->use_dense)
+    return lowered_kernel_name();
   return p ? p->kernel_name.c_str() : "";
 }
 
@@ -324,9 +330,22 @@ int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_de
     return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
   if (n_images == 0) return ESCOIN_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && !p->use_dense)
+    return launch_lowered(p, bottom_dev, bias_dev, top_dev, n_images, s);
   if (p->use_dense) return launch_dense(p, bottom_dev, bias_dev, top_dev, n_images, s);
   if (p->tiled.enabled) return launch_tiled(p, bottom_dev, bias_dev, top_dev, n_images, s);
   return launch_generic(p, bottom_dev, bias_dev, top_dev, n_images, s);
+}
+
+int escoin_gpu_sparse_csrmm(int M, int N, int K, int nnz, float alpha, const float *values,
+                            const int *rowptr, const int *colidx, const float *B, float beta, float *C,
+                            void *stream) {
+  if (M < 0 || N < 0 || K < 0 || nnz < 0) return fail(ESCOIN_EINVAL, "negative dimension");
+  if (M == 0 || N == 0) return ESCOIN_OK;
+  if (!rowptr || !C || (nnz > 0 && (!values || !colidx || !B))) return fail(ESCOIN_EINVAL, "null argument");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(ESCOIN_ENODEVICE, "no HIP device (there is no CPU fallback)");
+  return csrmm(M, N, K, alpha, values, rowptr, colidx, B, beta, C, (hipStream_t)stream);
 }
 
 }  // extern "C"

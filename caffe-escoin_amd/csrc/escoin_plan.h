@@ -82,6 +82,10 @@ struct escoin_plan {
   float *d_dense_w = nullptr;     // [M][Cg*KH*KW]
   bool use_dense = false;
 
+  // LOWERED_SPARSE comparator (sconv_lowered.hip): column buffer, grown on demand
+  float *d_col = nullptr;
+  size_t col_bytes = 0;
+
   size_t device_bytes = 0;
   std::string kernel_name = "(not aligned)";
 };
@@ -99,6 +103,13 @@ int tiled_build(escoin_plan *p, hipStream_t stream);  // fills p->tiled, uploads
 int launch_tiled(const escoin_plan *p, const float *bottom, const float *bias, float *top,
                  int n_images, hipStream_t stream);
 const char *tiled_kernel_name(const escoin_plan *p);
+
+// sconv_lowered.hip (conv_mode LOWERED_SPARSE: im2col + CSR x dense, the lowering baseline)
+int launch_lowered(escoin_plan *p, const float *bottom, const float *bias, float *top, int n_images,
+                   hipStream_t stream);
+int csrmm(int M, int N, int K, float alpha, const float *vals, const int *rowptr, const int *colidx,
+          const float *B, float beta, float *C, hipStream_t stream);
+const char *lowered_kernel_name();
 
 // dense_mfma.hip
 int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, float *top,

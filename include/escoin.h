@@ -100,7 +100,9 @@ ESCOIN_API long escoin_padded_len(const escoin_conv_desc *desc);
 ESCOIN_API int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan);
 ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
 
-/* Options: "kernel" = ESCOIN_KERNEL_*, "conv_mode" = ESCOIN_CONV_MODE_*,
+/* Options: "kernel" = ESCOIN_KERNEL_*, "conv_mode" = ESCOIN_CONV_MODE_SCONV / SCONV_PAR (the
+ * direct path; the two differ only in the reference's batching) or LOWERED_SPARSE (comparator:
+ * im2col + CSR x dense per image, base_conv_layer.cpp:724-736; may be switched after align),
  * "dense_gate" = 0/1 (1: reproduce the reference's per-layer gate that sends
  * density(group 0) > 0.2 to the dense GEMM path, base_conv_layer.cpp:750-755,805-811;
  * here the dense path is the fp32-MFMA implicit-GEMM kernel, ESCOIN_KERNEL_DENSE).
@@ -168,6 +170,15 @@ ESCOIN_API int escoin_gpu_stretch(const int *rowptr, int *colidx, int M, int hei
 /* copy_input_data<float>, math_functions.cu:729-766: dense image -> padded layout. */
 ESCOIN_API int escoin_copy_input_data(float *dst, const float *src, int num_channels, int height,
                            int width, int pad_h, int pad_w, void *stream);
+
+/* caffe_gpu_sparse_csrmm<float>, math_functions.cu:48-62 (cusparseScsrmm2 + cublasSgeam there):
+ * C[M x N] = alpha * A_csr[M x K] * B[K x N] + beta * C, all row-major on the device, 0-based
+ * CSR with ascending columns.  No transpose scratch: C comes out row-major directly.  The
+ * LOWERED_SPARSE comparator (conv_mode 1: im2col + this) is built on it; it is a baseline to
+ * measure the direct path against, not the product path. */
+ESCOIN_API int escoin_gpu_sparse_csrmm(int M, int N, int K, int nnz, float alpha, const float *values,
+                            const int *rowptr, const int *colidx, const float *B, float beta,
+                            float *C, void *stream);
 
 /* caffe_gpu_sparse_dense2csr<float>, math_functions.cu:103-152: device dense M x N ->
  * device CSR (0-based, ascending columns); *nnz_total written on the host. */

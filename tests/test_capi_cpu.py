@@ -64,8 +64,10 @@ def test_plan_lifecycle_and_options_on_host(pkg):
     assert plan.nnz() == 0 and plan.workspace_bytes == 0
     plan.set_option("kernel", pkg.KERNEL_GENERIC)
     plan.set_option("conv_mode", pkg.CONV_MODE_SCONV)
+    plan.set_option("conv_mode", pkg.CONV_MODE_LOWERED_SPARSE)   # the im2col + csrmm comparator
+    plan.set_option("conv_mode", pkg.CONV_MODE_SCONV_PAR)
     with pytest.raises(pkg.EscoinError):
-        plan.set_option("conv_mode", 0)              # LOWERED_GEMM is not this library's path
+        plan.set_option("conv_mode", 0)              # LOWERED_GEMM is the kernel option KERNEL_DENSE
     with pytest.raises(pkg.EscoinError):
         plan.set_option("no_such_option", 1)
     with pytest.raises(pkg.EscoinError):

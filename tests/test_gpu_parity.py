@@ -300,3 +300,61 @@ def test_dense_gate_follows_the_reference_threshold(pkg, oracle, synth, torch_cu
     got = plan.forward(torch.from_numpy(x).to(dev), None).cpu().numpy()
     assert rel_err(got, oracle.conv_forward(g, x, w, None, gate=False)) <= TOL
     plan.close()
+
+
+@pytest.mark.parametrize("path", golden_params())
+def test_lowered_sparse_comparator_is_bit_exact(pkg, torch_cuda, path):
+    """conv_mode LOWERED_SPARSE (im2col + CSR x dense, base_conv_layer.cpp:724-736): one fmaf per
+    nonzero in CSR order from 0, bias added once -- the oracle's arithmetic, so bit-exact."""
+    torch = torch_cuda
+    gf = Golden(path)
+    dev = torch.device("cuda:0")
+    plan = pkg.Plan(gf.desc(pkg), conv_mode=pkg.CONV_MODE_LOWERED_SPARSE)
+    plan.weight_align(gf.w)
+    assert plan.kernel_name == "escoin_csrmm_kernel"
+    top = plan.forward(torch.from_numpy(gf.x).to(dev),
+                       torch.from_numpy(gf.bias).to(dev) if gf.bias is not None else None)
+    torch.cuda.synchronize()
+    got = top.cpu().numpy()
+    assert got.shape == gf.top.shape
+    assert np.array_equal(got.view(np.uint32), gf.top.view(np.uint32)), rel_err(got, gf.top)
+    # the mode can be flipped on an aligned plan: back to the direct path
+    plan.set_option("conv_mode", pkg.CONV_MODE_SCONV_PAR)
+    assert plan.kernel_name != "escoin_csrmm_kernel"
+    top2 = plan.forward(torch.from_numpy(gf.x).to(dev),
+                        torch.from_numpy(gf.bias).to(dev) if gf.bias is not None else None)
+    torch.cuda.synchronize()
+    assert rel_err(top2.cpu().numpy(), gf.top) <= TOL
+    plan.close()
+
+
+def test_gpu_sparse_csrmm_entry_point(pkg, synth, torch_cuda):
+    """escoin_gpu_sparse_csrmm (caffe_gpu_sparse_csrmm, math_functions.cu:48-62) against numpy,
+    ragged sizes, alpha / beta."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(5)
+    for (M, N, K, dens) in [(7, 13, 9, 0.5), (64, 784, 576, 0.1), (3, 1, 4, 1.0), (5, 260, 33, 0.0), (16, 1024, 64, 0.3)]:
+        A = (rng.rand(M, K) < dens) * rng.uniform(-1, 1, (M, K))
+        A = A.astype(np.float32)
+        rowptr = np.zeros(M + 1, np.int32)
+        cols, vals = [], []
+        for m in range(M):
+            nz = np.nonzero(A[m])[0]
+            cols.extend(nz.tolist())
+            vals.extend(A[m, nz].tolist())
+            rowptr[m + 1] = len(cols)
+        B = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+        C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+        d_rp, d_ci, d_va = t(rowptr, np.int32), t(np.array(cols + [0], np.int32), np.int32), t(np.array(vals + [0], np.float32), np.float32)
+        d_B, d_C = t(B, np.float32), t(C0, np.float32)
+        for (alpha, beta) in [(1.0, 0.0), (0.5, 2.0)]:
+            d_C.copy_(t(C0, np.float32))
+            pkg.check(pkg.lib().escoin_gpu_sparse_csrmm(M, N, K, len(cols), alpha, C.c_void_p(d_va.data_ptr()),
+                                                        C.c_void_p(d_rp.data_ptr()), C.c_void_p(d_ci.data_ptr()),
+                                                        C.c_void_p(d_B.data_ptr()), beta, C.c_void_p(d_C.data_ptr()), None),
+                      "escoin_gpu_sparse_csrmm")
+            torch.cuda.synchronize()
+            want = alpha * (A.astype(np.float64) @ B.astype(np.float64)) + beta * C0
+            assert rel_err(d_C.cpu().numpy(), want.astype(np.float32)) <= 1e-5, (M, N, K, alpha, beta)

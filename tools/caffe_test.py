@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""`caffe test -conv_mode {2,3}` for the sparse convolution layers only.
+"""`caffe test -conv_mode {1,2,3}` for the sparse convolution layers only.
 
 The reference's `caffe test` (tools/caffe.cpp:262-362) loads a model + a pruned .caffemodel,
 runs `-iterations` forward passes and prints "[cxh] Total CONV time" per pass
@@ -49,7 +49,8 @@ def main():
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--weights", default=None, help=".caffemodel with pruned weights (by layer name)")
     ap.add_argument("--export", default=None, help="write the synthetic pruned model here and exit")
-    ap.add_argument("--conv_mode", type=int, default=3, choices=[2, 3])
+    ap.add_argument("--conv_mode", type=int, default=3, choices=[1, 2, 3],
+                    help="1 = LOWERED_SPARSE comparator (im2col + csrmm), 2/3 = direct sparse convolution")
     ap.add_argument("--iterations", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--sparsity", type=float, default=None)

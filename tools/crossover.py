@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Sparse (tiled, VALU) vs dense (fp32 MFMA implicit GEMM) forward time as a function of weight
-sparsity -- BASELINE.json configs[4]: GoogLeNet-v1 1x1 convs and the dense-fallback crossover.
+sparsity -- BASELINE.json configs[4]: GoogLeNet-v1 1x1 convs and the dense-fallback crossover --
+and, at the layer's nominal sparsity, the lowering baseline the reference compares against
+(conv_mode LOWERED_SPARSE: im2col + CSR x dense, run.sh:8-12).
 Runs on the GPU box:  python tools/crossover.py [--batch 256] > profiles/<tag>_crossover.md"""
 import argparse
 import os
@@ -37,8 +39,9 @@ def main():
               synth.resnet50_3x3(N=args.batch)[2], synth.alexnet(N=128)[1]]
     sparsities = [0.0, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95]
     print("| layer (C@HxW -> M, K) | dense MFMA us (TFLOP/s dense) | " +
-          " | ".join("sparse @%d%% us" % round(100 * s) for s in sparsities) + " | crossover |")
-    print("|---|---|" + "---|" * (len(sparsities) + 1))
+          " | ".join("sparse @%d%% us" % round(100 * s) for s in sparsities) +
+          " | crossover | lowered csrmm @nominal us (direct speedup) |")
+    print("|---|---|" + "---|" * (len(sparsities) + 2))
     for s in layers:
         x = torch.rand((s.N, s.C, s.H, s.W), device=dev) * 2 - 1
         oh, ow = synth.out_hw(s)
@@ -60,9 +63,17 @@ def main():
             row.append("%.0f" % t)
             if cross is None and t < td:
                 cross = sp
-        print("| %s (%d@%dx%d -> %d, %dx%d) | %.0f (%.1f) | %s | %s |" %
+        # lowering baseline and direct path at the layer's own sparsity
+        pl = pkg.Plan(pkg.ConvDesc.from_shape(s), conv_mode=pkg.CONV_MODE_LOWERED_SPARSE)
+        pl.weight_align(synth.pruned_weights(s, 7))
+        tl = time_plan(torch, pl, x, bias, top, reps=5)
+        pl.set_option("conv_mode", pkg.CONV_MODE_SCONV_PAR)
+        tn = time_plan(torch, pl, x, bias, top)
+        pl.close()
+        print("| %s (%d@%dx%d -> %d, %dx%d) | %.0f (%.1f) | %s | %s | %.0f @%d%% (%.1fx) |" %
               (s.name, s.C, s.H, s.W, s.M, s.KH, s.KW, td, dense_flops / td / 1e6, " | ".join(row),
-               ("sparse wins from %d%%" % round(100 * cross)) if cross is not None else "dense wins everywhere"))
+               ("sparse wins from %d%%" % round(100 * cross)) if cross is not None else "dense wins everywhere",
+               tl, round(100 * s.sparsity), tl / tn))
         sys.stdout.flush()
 
 
