@@ -106,7 +106,8 @@ def body2(L, n, p, band):
     # The two waves of a SIMD are arbitrated oldest-first: left alone, the younger one runs ~25 %
     # slower all kernel long and every block waits for it.  Alternating priority by group parity
     # lets whichever wave is behind win its even groups.
-    A("s_setprio %d" % (1 - p))
+    if "noprio" not in ABL:
+        A("s_setprio %d" % (1 - p))
     A("s_set_gpr_idx_idx 0")
     if n > 3:
         A("ds_read_b128 v[%d:%d], v%d offset:16" % (P1, P1 + 3, VP))
@@ -193,6 +194,9 @@ def emit_macro(out, name, lines):
 
 
 def main():
+    import os
+    if os.environ.get("ESC_GEN_NOPRIO"):
+        ABL.add("noprio")
     out = sys.stdout
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
