@@ -189,6 +189,10 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
         }
         hdr[7] = (uint32_t)(ws.words.size() * 4);
         const size_t body = ws.words.size();
+        // the body starts with a copy of the header: it reaches the wave's staging area with the
+        // quads, one block ahead, and is read from there (a scalar load per block sat on the
+        // critical path)
+        ws.words.insert(ws.words.end(), hdr, hdr + kUnitHdrDwords);
         for (int k = 0; k < tg; ++k) {
           const Group &gr = groups[k];
           const int n = (int)gr.recs.size();

@@ -64,13 +64,15 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, 
 // ---- the weight stream: staged in LDS with the planes, values read as broadcast quads ---------
 //
 // One unit per (conv group, oc-group, input-channel block), in two parts:
-//   unit_hdr[8 * unit + ...]   (read with scalar loads, one s_load_dwordx8 per block and wave)
+//   unit_hdr[8 * unit + ...]   (also the first 32 bytes of the body: the kernel reads it from the
+//                               staging area; the table itself is read once, for block 0's offset)
 //     [0]     what groups 0 and 1 need before any quad has been read: accumulator of group 0's
 //             record 0 (bits 0..6), row offset / 32 of group 0 (8..18) and of group 1 (21..31)
 //     [1..6]  END_6, END_5, ..., END_1: END_n = number of groups with >= n records (the groups of
 //             a unit are sorted by record count, descending; END_1 = number of groups)
 //     [7]     byte offset of the unit's body in `words`
-//   body (copied into the wave's LDS staging area by LDS-DMA one block ahead)
+//   body (copied into the wave's LDS staging area by LDS-DMA one block ahead): the 8 header
+//   dwords, then
 //     per group one quad [meta, v0, v1, v2]; groups with more than 3 records a second quad
 //     [meta2, v3, v4, v5]; the kernel reads them as broadcast ds_read_b128 and feeds the values to
 //     v_pk_fma_f32 straight from the VGPR pair (op_sel picks the half).

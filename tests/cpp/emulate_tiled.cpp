@@ -113,6 +113,9 @@ static int run(const Case &cs) {
               const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
               const uint32_t *hdr = &ws2.unit_hdr[ui * kUnitHdrDwords];
               const uint32_t *body = &ws2.words[hdr[7] / 4];
+              for (int d = 0; d < kUnitHdrDwords; ++d)
+                if (body[d] != hdr[d]) { printf("body does not start with the header\n"); return 3; }
+              body += kUnitHdrDwords;
               if (hdr[0] & 0x80) { printf("bit 7 of the lead word is not clear\n"); return 3; }
               uint32_t row_cur = (hdr[0] >> 8) & 0x7FF, ix0 = hdr[0] & 127, row_next = hdr[0] >> 21;
               size_t pos = 0;   // dword position in the body
@@ -153,7 +156,7 @@ static int run(const Case &cs) {
                 }
               }
               if (row_cur != 0 || row_next != 0 || ix0 != 0) { printf("leads past the last group are not empty\n"); return 3; }
-              if ((int)(pos * 4) > ws2.max_body_bytes) { printf("body longer than max_body_bytes\n"); return 3; }
+              if ((int)(pos * 4) + 4 * kUnitHdrDwords > ws2.max_body_bytes) { printf("body longer than max_body_bytes\n"); return 3; }
             }
           }
         }
