@@ -20,11 +20,13 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
   t.H = g.H; t.W = g.W; t.OH = g.OH; t.OW = g.OW;
   // epilogue shifts: s = kc - pad_w must satisfy |s| <= 4 (one neighbouring quad)
   if (g.KW < 1 || g.KW > 5 || g.pad_w > 4 || g.KW - 1 - g.pad_w > 4) return t;
-  if (g.W > 256 || g.OH < 1 || g.OW < 1) return t;
+  if (g.W > 256 || g.OW > 256 || g.OH < 1 || g.OW < 1) return t;
   if (waves_per_wg != 1 && waves_per_wg != 2 && waves_per_wg != 4 && waves_per_wg != 8) return t;
   t.KW = g.KW;
   t.KH = g.KH;
-  t.S4 = std::max(2, next_pow2((g.W + 3) / 4));   // rows are >= 32 bytes (the stream stores offsets / 32)
+  // a lane quad is an input quad AND an output quad: the row must hold the wider of the two
+  // (OW > W when pad > (KW - 1) / 2); rows are >= 32 bytes (the stream stores offsets / 32)
+  t.S4 = std::max(2, next_pow2((std::max(g.W, g.OW) + 3) / 4));
   t.RS = 4 * t.S4;
   t.rows_per_slab = 64 / t.S4;
   // Output channels per wave.  The accumulator file bounds it (KW=1:24 2:12 3:8 4:6 5:4); within

@@ -236,6 +236,8 @@ int main() {
       {5, 30, 7, 7, 48, 1, 1, 0, 0, 1, 0.9f, 8, 65536},     // pointwise 7x7 -> 49 x 1, few channels/wave
       {300, 6, 7, 7, 12, 1, 1, 0, 0, 1, 0.8f, 8, 65536},    // batch > CUs: several images per workgroup
       {3, 6, 13, 13, 10, 1, 1, 0, 0, 2, 0.7f, 8, 65536},    // pointwise 13x13 (169 = 13^2), groups
+      {3, 8, 21, 6, 7, 5, 5, 4, 4, 1, 0.9f, 8, 65536},      // pad 4 with 5x5: OW = 10 > W = 6
+      {2, 4, 5, 7, 6, 3, 3, 2, 2, 1, 0.5f, 8, 65536},       // pad 2 with 3x3: OW = 9 > RS(W) = 8
   };
   int bad = 0;
   for (const Case &c : cases) bad += run(c) != 0;

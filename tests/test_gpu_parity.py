@@ -358,3 +358,33 @@ def test_gpu_sparse_csrmm_entry_point(pkg, synth, torch_cuda):
             torch.cuda.synchronize()
             want = alpha * (A.astype(np.float64) @ B.astype(np.float64)) + beta * C0
             assert rel_err(d_C.cpu().numpy(), want.astype(np.float32)) <= 1e-5, (M, N, K, alpha, beta)
+
+
+@pytest.mark.parametrize("seed", [20260117, 7, 424242])
+def test_randomised_tiled_geometries(pkg, oracle, synth, torch_cuda, seed):
+    """Seeded random shapes for the tiled kernel's stream walk: dense rows (groups of 4-6 records,
+    rows split over several groups), all-pruned channel blocks (empty units), channel counts that
+    leave waves idle or half full, batches that leave tile slots empty, every kernel width."""
+    rng = np.random.RandomState(seed)
+    S = synth.shape
+    checked = 0
+    for k in range(48):
+        K = int(rng.choice([1, 1, 2, 3, 3, 3, 4, 5]))
+        pad = int(rng.randint(0, K)) if K > 1 else 0
+        H = int(rng.randint(max(K - 2 * pad, 1), 40))
+        W = int(rng.randint(max(K - 2 * pad, 1), 70))
+        group = int(rng.choice([1, 1, 1, 2, 3]))
+        C = group * int(rng.randint(1, 24))
+        M = group * int(rng.randint(1, 40))
+        N = int(rng.randint(1, 12))
+        sp = float(rng.choice([0.0, 0.3, 0.6, 0.8, 0.9, 0.97, 1.0]))
+        s = S("rnd%d" % k, N, C, H, W, M, K, pad=pad, group=group, sparsity=sp, bias=bool(rng.randint(2)))
+        w, b, x = synth.pruned_weights(s, 300 + k), synth.bias_vector(s, 400 + k), synth.activations(s, 500 + k)
+        if sp == 0.9 and C // group > 2:
+            w[:, : (C // group) // 2] = 0.0      # whole input-channel blocks without a nonzero
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
+        want = oracle.conv_forward(g, x, w, b, gate=False)
+        got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, pkg.KERNEL_AUTO)
+        assert rel_err(got, want) <= TOL, "%s %s via %s: %g" % (s.name, (N, C, H, W, M, K, pad, group, sp), name, rel_err(got, want))
+        checked += "tiled" in name
+    assert checked >= 40      # nearly all of these must have gone down the tiled path
