@@ -5,10 +5,15 @@
 // Here the column matrix is never materialised: per conv group
 //     C[Mg x P] = A[Mg x K] * B[K x P],   K = Cg*KH*KW,  P = N*OH*OW,
 // A = the dense weights, B = the im2col view gathered on the fly (any stride / pad / dilation).
-// Workgroup = 4 waves computing a 64 x 128 tile; each wave owns 32 x 64 = two 32x32 fp32
-// accumulators of v_mfma_f32_32x32x2_f32 (exact fp32: one fmaf per product, k ascending);
-// operands are staged through LDS k-major so that a lane's A[i][k] / B[k][j] fragment is one
-// conflict-free ds_read_b32.  Bias and ReLU are fused in the epilogue.
+//
+// Workgroup = 4 waves on a (64 * WROWS) x 128 tile, WROWS = 2 (waves 2 x 2, 64 x 64 each) or 1
+// (waves 1 x 4, 64 x 32 each, for layers with <= 64 output channels per group).  A wave's tile is
+// 2 x {2,1} blocks of v_mfma_f32_32x32x2_f32 (exact fp32: one fmaf per product, k ascending), so
+// a k-pair costs 4 (3) LDS fragment reads for 4 (2) MFMAs.  Operands are staged through LDS
+// k-major -- a lane's A[i][k] / B[k][j] fragment is one conflict-free ds_read_b32 -- in k-steps of
+// 16, double buffered: the global loads of step s+1 (A along k, B gathered along the pixel axis,
+// coalesced) fly under the 32 (16) MFMAs of step s and there is one barrier per step.  Bias and
+// ReLU are fused in the epilogue.
 #include <hip/hip_runtime.h>
 
 #include "escoin_plan.h"
@@ -17,7 +22,7 @@ namespace escoin {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 64, kBN = 128, kBK = 8;
+constexpr int kBN = 128, kBK = 16, kLdsPad = 4;
 
 struct DenseArgs {
   const float *__restrict__ in;
@@ -29,20 +34,27 @@ struct DenseArgs {
   int Cg, Mg, K, P, relu;
 };
 
+template <int WROWS>
 __global__ void __launch_bounds__(256) escoin_dense_mfma_kernel(DenseArgs a) {
-  __shared__ float sA[kBK][kBM + 4];   // +4: rows land on different banks for the staging writes
-  __shared__ float sB[kBK][kBN + 4];
+  constexpr int BM = 64 * WROWS;
+  constexpr int WCOLS = 4 / WROWS;           // waves along the pixel axis
+  constexpr int WN = kBN / WCOLS;            // columns per wave: 64 or 32
+  constexpr int NB = WN / 32;                // 32-column MFMA blocks per wave
+  constexpr int A_PER = BM * kBK / 256;      // A elements staged per thread and step: 8 or 4
+  constexpr int B_PER = kBN * kBK / 256;     // B elements staged per thread and step: 8
+  __shared__ float sA[2][kBK][BM + kLdsPad];
+  __shared__ float sB[2][kBK][kBN + kLdsPad];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;          // 2 x 2 waves: 32 rows x 64 cols each
+  const int wm = wave / WCOLS, wn = wave % WCOLS;
   const int cg = blockIdx.z;
-  const int m0 = blockIdx.y * kBM;                  // first output channel (group-local)
+  const int m0 = blockIdx.y * BM;                   // first output channel (group-local)
   const int p0 = blockIdx.x * kBN;                  // first flattened output pixel
   const int khw = a.KH * a.KW;
   const int ohw = a.OH * a.OW;
 
-  // ---- B staging: this thread gathers column p_local for k_local = kb, kb+2, kb+4, kb+6 ----
+  // ---- B staging: this thread gathers column p_local for k_local = kb + 2 q, q < B_PER ----
   const int p_local = tid & (kBN - 1);
   const int kb = tid >> 7;                          // 0 or 1
   const int p = p0 + p_local;
@@ -57,24 +69,34 @@ __global__ void __launch_bounds__(256) escoin_dense_mfma_kernel(DenseArgs a) {
   const int ih0 = oh * a.stride_h - a.pad_h, iw0 = ow * a.stride_w - a.pad_w;
   const float *img = a.in + ((size_t)n * a.C + (size_t)cg * a.Cg) * a.H * a.W;
 
-  // ---- A staging: thread loads A[m0 + (tid>>2)][k0 + 2*(tid&3) + {0,1}] ----
-  const int am = tid >> 2, ak = (tid & 3) * 2;
+  // ---- A staging: thread loads A[m0 + am][k0 + ak .. ak + A_PER) (contiguous in memory) ----
+  constexpr int A_TPR = kBK / A_PER;                // threads per A row: 2 or 4
+  const int am = tid / A_TPR, ak = (tid % A_TPR) * A_PER;
   const bool am_ok = m0 + am < a.Mg;
   const float *wrow = a.w + ((size_t)cg * a.Mg + (am_ok ? m0 + am : 0)) * a.K;
+  const bool a_vec = (a.K & 3) == 0;                // rows 16-byte aligned (hipMalloc'd base)
 
-  f32x16 acc0 = {0}, acc1 = {0};
-  float av0, av1, bv[4];
-  // gathers one k-step's operands into registers (software pipelined: the loads of step k+1 fly
-  // under the MFMAs of step k)
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x16{0};
+
+  float av[A_PER], bv[B_PER];
   auto gather = [&](int k0) {
-    av0 = 0.f;
-    av1 = 0.f;
-    if (am_ok) {
-      if (k0 + ak < a.K) av0 = wrow[k0 + ak];
-      if (k0 + ak + 1 < a.K) av1 = wrow[k0 + ak + 1];
+#pragma unroll
+    for (int i = 0; i < A_PER; i += 4) {
+      const int k = k0 + ak + i;
+      if (am_ok && a_vec && k + 3 < a.K) {
+        const float4 v = *reinterpret_cast<const float4 *>(wrow + k);
+        av[i] = v.x; av[i + 1] = v.y; av[i + 2] = v.z; av[i + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[i + e] = (am_ok && k + e < a.K) ? wrow[k + e] : 0.f;
+      }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < B_PER; ++q) {
       const int k = k0 + kb + 2 * q;
       float v = 0.f;
       if (p_ok && k < a.K) {
@@ -88,43 +110,58 @@ __global__ void __launch_bounds__(256) escoin_dense_mfma_kernel(DenseArgs a) {
       bv[q] = v;
     }
   };
-  gather(0);
-  for (int k0 = 0; k0 < a.K; k0 += kBK) {
-    __syncthreads();                                // previous step's fragments are consumed
-    sA[ak][am] = av0;
-    sA[ak + 1][am] = av1;
+  auto stage = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sB[kb + 2 * q][p_local] = bv[q];
-    __syncthreads();
-    if (k0 + kBK < a.K) gather(k0 + kBK);
+    for (int i = 0; i < A_PER; ++i) sA[buf][ak + i][am] = av[i];
+#pragma unroll
+    for (int q = 0; q < B_PER; ++q) sB[buf][kb + 2 * q][p_local] = bv[q];
+  };
+
+  gather(0);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < a.K; k0 += kBK, buf ^= 1) {
+    const bool more = k0 + kBK < a.K;
+    if (more) gather(k0 + kBK);                     // flies under the MFMAs below
 #pragma unroll
     for (int kk = 0; kk < kBK; kk += 2) {
       // 32x32x2: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
       const int ks = kk + (lane >> 5);
-      const float fa = sA[ks][wm * 32 + (lane & 31)];
-      const float fb0 = sB[ks][wn * 64 + (lane & 31)];
-      const float fb1 = sB[ks][wn * 64 + 32 + (lane & 31)];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb1, acc1, 0, 0, 0);
+      const float fa0 = sA[buf][ks][wm * 64 + (lane & 31)];
+      const float fa1 = sA[buf][ks][wm * 64 + 32 + (lane & 31)];
+      float fb[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) fb[j] = sB[buf][ks][wn * WN + 32 * j + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb[j], acc[1][j], 0, 0, 0);
+      }
     }
+    if (more) stage(buf ^ 1);                       // the other buffer: last read one step ago
+    __syncthreads();
   }
 
   // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int pj = p0 + wn * 64 + half * 32 + (lane & 31);
+  for (int j = 0; j < NB; ++j) {
+    const int pj = p0 + wn * WN + 32 * j + (lane & 31);
     if (pj >= a.P) continue;
     const int nn = pj / ohw;
     const int rr = pj - nn * ohw;
     float *obase = a.out + ((size_t)nn * a.M + (size_t)cg * a.Mg) * ohw + rr;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int m = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      if (m >= a.Mg) continue;
-      float v = half ? acc1[reg] : acc0[reg];
-      if (a.bias) v += a.bias[cg * a.Mg + m];
-      if (a.relu) v = fmaxf(v, 0.f);
-      obase[(size_t)m * ohw] = v;
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (m >= a.Mg) continue;
+        float v = acc[i][j][reg];
+        if (a.bias) v += a.bias[cg * a.Mg + m];
+        if (a.relu) v = fmaxf(v, 0.f);
+        obase[(size_t)m * ohw] = v;
+      }
     }
   }
 }
@@ -143,9 +180,11 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   const long P = (long)n_images * g.OH * g.OW;
   if (P >= (1l << 31)) return fail(ESCOIN_EINVAL, "dense kernel: N*OH*OW does not fit 31 bits");
   a.P = (int)P;
-  dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((g.Mg + kBM - 1) / kBM), (unsigned)g.d.group);
+  const int bm = g.Mg <= 64 ? 64 : 128;
+  dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((g.Mg + bm - 1) / bm), (unsigned)g.d.group);
   if (grid.y > 65535u || grid.z > 65535u) return fail(ESCOIN_EINVAL, "dense kernel: grid too large");
-  hipLaunchKernelGGL(escoin_dense_mfma_kernel, grid, dim3(256), 0, stream, a);
+  if (bm == 64) hipLaunchKernelGGL(escoin_dense_mfma_kernel<1>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(escoin_dense_mfma_kernel<2>, grid, dim3(256), 0, stream, a);
   ESCOIN_HIP_TRY(hipGetLastError());
   return ESCOIN_OK;
 }
