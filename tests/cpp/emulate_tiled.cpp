@@ -108,7 +108,7 @@ static int run(const Case &cs) {
             const int ocg = ocblk * t.oc_waves + ow_;
             if (ocg >= t.n_ocg) continue;
             {
-              // format 2: the unit's body sits in the wave's staging area; row offset and first
+              // the unit's body sits in the wave's staging area; row offset and first
               // accumulator of a group come from the previous group's meta word
               const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
               const uint32_t *hdr = &ws2.unit_hdr[ui * kUnitHdrDwords];
