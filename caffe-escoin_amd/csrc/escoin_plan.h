@@ -48,6 +48,7 @@ struct TiledConfig {
   int slots = 0;       // records per row group in the weight stream
   size_t lds_bytes = 0;
   int lds_budget = 0;  // plane-buffer budget the tiling was chosen with
+  float density = 0.f; // nonzero fraction of the weights the tiling was chosen with
   int stage_bytes = 0; // LDS bytes of one wave's weight-stream staging area
 };
 

@@ -2,6 +2,7 @@
 #include "stream_builder.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace escoin {
@@ -14,8 +15,10 @@ static int next_pow2(int v) {
 
 namespace {
 
-// The tiling of one concrete (H, W) cut of the image.
-Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu) {
+// One candidate tiling of a concrete (H, W) cut of the image: `passes` workgroup columns per conv
+// group (0: as few as the accumulator file allows) and, for layers whose images fit a workgroup
+// tile, `nseg` whole images per workgroup (0: as many as fit).
+Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int passes, int nseg) {
   Tiling t;
   t.H = g.H; t.W = g.W; t.OH = g.OH; t.OW = g.OW;
   // epilogue shifts: s = kc - pad_w must satisfy |s| <= 4 (one neighbouring quad)
@@ -35,11 +38,13 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
   // per workgroup (more workgroups for the same batch) and every wave of it shares one staged
   // input tile, instead of a few workgroups whose waves each own 24 channels' worth of nothing.
   const int gmax = kAccRegsPerTile / (4 * g.KW);
+  const int mg = std::max(1, g.Mg);
   t.waves = waves_per_wg;
   t.oc_waves = 1;
-  while (t.oc_waves * 2 <= waves_per_wg && t.oc_waves * 2 <= std::max(1, g.Mg)) t.oc_waves *= 2;
-  const int passes = (std::max(1, g.Mg) + gmax * t.oc_waves - 1) / (gmax * t.oc_waves);
-  t.G = (std::max(1, g.Mg) + t.oc_waves * passes - 1) / (t.oc_waves * passes);
+  while (t.oc_waves * 2 <= waves_per_wg && t.oc_waves * 2 <= mg) t.oc_waves *= 2;
+  const int min_passes = (mg + gmax * t.oc_waves - 1) / (gmax * t.oc_waves);
+  passes = std::max(passes, min_passes);
+  t.G = (mg + t.oc_waves * passes - 1) / (t.oc_waves * passes);
   t.n_ocg = (g.Mg + t.G - 1) / t.G;
   t.pix_waves = waves_per_wg / t.oc_waves;
   t.n_ocblk = (t.n_ocg + t.oc_waves - 1) / t.oc_waves;
@@ -47,20 +52,9 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
   if (g.OH <= t.rows_per_wg) {
     t.band_mode = false;
     t.tr = g.OH;
-    t.nseg = t.rows_per_wg / g.OH;
+    const int fit = t.rows_per_wg / g.OH;
+    t.nseg = nseg > 0 ? std::min(nseg, fit) : fit;
     t.bands = 1;
-    // Whole images per workgroup: as many as fit, unless the batch then leaves compute units
-    // without a workgroup.  A workgroup's walk over the weight stream costs the same whether its
-    // lanes are full or not, so the number of rounds (workgroups / CUs) is what counts; among
-    // the choices with the fewest rounds the smallest tile stages the least input per workgroup.
-    const long gy = (long)g.group * t.n_ocblk;
-    auto rounds = [&](int nseg) { return (((long)g.N + nseg - 1) / nseg * gy + n_cu - 1) / n_cu; };
-    const long best = rounds(t.nseg);
-    for (int ns = 1; ns < t.nseg; ++ns)
-      if (rounds(ns) == best) {
-        t.nseg = ns;
-        break;
-      }
   } else {
     t.band_mode = true;
     t.tr = t.rows_per_wg;
@@ -80,6 +74,54 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
   t.planes_bytes = t.icb * per_ch;
   t.ok = true;
   return t;
+}
+
+// Estimated microseconds per launch (constants measured on MI355X): a workgroup
+// pays ~1.2 us per block (barrier, DMA issue, loop prologue), ~60 ns per nonempty input row and
+// ~18 ns per nonzero in its waves' stream walk -- the same whether its lanes are full or not --
+// stages its planes at ~50 GB/s under that walk, and the launch takes as many rounds as there are
+// workgroups per CU.
+double launch_cost_us(const ConvGeom &g, const Tiling &t, int n_cu) {
+  const double d = g.density > 0.f ? g.density : 0.1;
+  const double rows = (double)g.Cg * g.KH;
+  const double nonempty = 1.0 - std::pow(1.0 - d, (double)t.G * g.KW);
+  const double walk = rows * nonempty * 0.060 + rows * g.KW * t.G * d * 0.018;
+  const double dma = (double)g.Cg * t.plane_ch_floats * 4.0 / 50e3;
+  const double epilogue = 0.15 * t.G * kTilesPerLane;
+  const double per_tile = t.n_icb * 1.2 + std::max(walk, dma) + epilogue;
+  const long tiles = t.band_mode ? (long)g.N * t.bands : ((long)g.N + t.nseg - 1) / t.nseg;
+  const long cus = std::max(1, n_cu);
+  // persistent workgroups: grid.x = CUs / grid.y of them walk the tiles; when grid.y alone exceeds
+  // the CUs the workgroups run in several waves
+  const long gy = (long)g.group * t.n_ocblk;
+  const long gx = std::min(tiles, std::max<long>(1, cus / gy));
+  const long tiles_per_wg = (tiles + gx - 1) / gx;
+  const long waves_of_wgs = (gx * gy + cus - 1) / cus;
+  return (double)tiles_per_wg * per_tile * (double)waves_of_wgs;
+}
+
+// The tiling of one concrete (H, W) cut: the cheapest of the candidates (more passes = fewer
+// output channels and a shorter stream per wave, but the input staged once more; fewer images per
+// workgroup = more workgroups for small batches, but emptier lanes).
+Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu) {
+  Tiling best = tile_with(g, waves_per_wg, lds_budget_bytes, 0, 0);
+  if (!best.ok) return best;
+  double best_cost = launch_cost_us(g, best, n_cu);
+  const int base_passes = best.n_ocblk;
+  const int fit = best.band_mode ? 1 : best.nseg;
+  for (int passes = base_passes; passes <= 8 * base_passes; ++passes) {
+    for (int nseg = fit; nseg >= 1; --nseg) {
+      const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, passes, nseg);
+      if (!t.ok || t.G < 1) continue;
+      const double c = launch_cost_us(g, t, n_cu);
+      if (c < best_cost * 0.97) {      // a clear win only: ties keep fewer passes / fuller tiles
+        best = t;
+        best_cost = c;
+      }
+    }
+    if (best.G == 1) break;
+  }
+  return best;
 }
 
 }  // namespace

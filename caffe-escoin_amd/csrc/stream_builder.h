@@ -28,6 +28,7 @@ constexpr int kAccRegsPerTile = 96;   // accumulator VGPRs per tile (192 in all)
 struct ConvGeom {
   int N, C, H, W, M, KH, KW, pad_h, pad_w, group;
   int OH, OW, Cg, Mg;
+  float density = 0.f;   // nonzero fraction of the weights (0: unknown); steers the tiling choice
 };
 
 struct Tiling {
@@ -57,8 +58,8 @@ struct Tiling {
 // Picks the tiling for a geometry; .ok == false when the tiled kernel does not apply
 // (stride/dilation != 1 are filtered by the caller; here: KW > 5, W > 256, ...).
 // lds_budget_bytes bounds the input planes only; the stream region is added on top.
-// n_cu: compute units of the device (sizes the pixel tile of small layers so that the batch
-// g.N fills the chip).
+// n_cu: compute units of the device.  Among the candidate tilings (passes over the output
+// channels x images per workgroup) the one with the lowest estimated launch time is taken.
 Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu = 256);
 
 // ---- the weight stream: staged in LDS with the planes, values read as broadcast quads ---------

@@ -23,7 +23,7 @@ static float frand() {
   return ((rng_state >> 8) & 0xFFFF) / 32768.0f - 1.0f;
 }
 
-struct Case { int N, C, H, W, M, KH, KW, ph, pw, group; float sparsity; int waves; int lds; };
+struct Case { int N, C, H, W, M, KH, KW, ph, pw, group; float sparsity; int waves; int lds; int ncu = 1; };
 
 static int run(const Case &cs) {
   ConvGeom g{cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, 0, 0, 0, 0};
@@ -31,7 +31,10 @@ static int run(const Case &cs) {
   g.OW = cs.W + 2 * cs.pw - cs.KW + 1;
   g.Cg = cs.C / cs.group;
   g.Mg = cs.M / cs.group;
-  Tiling t = choose_tiling(g, cs.waves, cs.lds);
+  g.density = 1.0f - cs.sparsity;
+  // ncu = 1 (default): as on a full chip with a large batch, the fewest passes win; the cases
+  // with ncu = 256 see a nearly empty chip and spread the channels over many workgroups
+  Tiling t = choose_tiling(g, cs.waves, cs.lds, cs.ncu);
   if (!t.ok) { printf("tiling rejected\n"); return 2; }
   const int kdim = g.Cg * g.KH * g.KW;
   std::vector<float> w((size_t)g.M * kdim), x((size_t)g.N * g.C * g.H * g.W), bias(g.M);
@@ -238,6 +241,9 @@ int main() {
       {3, 6, 13, 13, 10, 1, 1, 0, 0, 2, 0.7f, 8, 65536},    // pointwise 13x13 (169 = 13^2), groups
       {3, 8, 21, 6, 7, 5, 5, 4, 4, 1, 0.9f, 8, 65536},      // pad 4 with 5x5: OW = 10 > W = 6
       {2, 4, 5, 7, 6, 3, 3, 2, 2, 1, 0.5f, 8, 65536},       // pad 2 with 3x3: OW = 9 > RS(W) = 8
+      {2, 5, 56, 56, 70, 3, 3, 1, 1, 1, 0.9f, 8, 65536, 256},   // empty chip: one channel per wave, 9 passes
+      {5, 30, 7, 7, 48, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 256},    // empty chip, pointwise
+      {40, 16, 7, 7, 64, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 8},     // 8 CUs: images per workgroup vs passes
   };
   int bad = 0;
   for (const Case &c : cases) bad += run(c) != 0;
