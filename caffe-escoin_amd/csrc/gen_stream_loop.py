@@ -69,36 +69,35 @@ def pk4v(L, r, p):
                  % (acc, acc + 1, pair, pair + 1, x, x + 1, acc, acc + 1, sel, sel))
 
 
-def prefetch2(L, p_next, stride, band):
+def prefetch2(L, p_next, p0_off, advance, band):
     """LDS reads of the next group: its two input quads (row offset / 32 in s[HDR2]) and its first
-    payload quad.  Runs with GPR index 0."""
+    payload quad (at v[VP] + p0_off; v[VP] then moves on by `advance` bytes).  Runs with GPR
+    index 0."""
     A = L.append
-    if "noxp" in ABL:
-        if stride:
-            A("ds_read_b128 v[%d:%d], v%d offset:%d" % (P0[p_next], P0[p_next] + 3, VP, stride))
-            A("v_add_u32 v%d, %d, v%d" % (VP, stride, VP))
+    if "noxp" not in ABL:
+        A("v_lshl_add_u32 v%d, s%d, 5, %%[lbA]" % (VA, HDR2))
+        if band:
+            A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
+            A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[p_next], XB[p_next] + 3, VA))
         else:
-            A("ds_read_b128 v[%d:%d], v%d" % (P0[p_next], P0[p_next] + 3, VP))
-        return
-    A("v_lshl_add_u32 v%d, s%d, 5, %%[lbA]" % (VA, HDR2))
-    if band:
-        A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
-        A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[p_next], XB[p_next] + 3, VA))
-    else:
-        A("v_lshl_add_u32 v%d, s%d, 5, %%[lbB]" % (VB, HDR2))
-        A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
-        A("ds_read_b128 v[%d:%d], v%d" % (XB[p_next], XB[p_next] + 3, VB))
-    if stride:
-        A("ds_read_b128 v[%d:%d], v%d offset:%d" % (P0[p_next], P0[p_next] + 3, VP, stride))
-        A("v_add_u32 v%d, %d, v%d" % (VP, stride, VP))
+            A("v_lshl_add_u32 v%d, s%d, 5, %%[lbB]" % (VB, HDR2))
+            A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
+            A("ds_read_b128 v[%d:%d], v%d" % (XB[p_next], XB[p_next] + 3, VB))
+    if p0_off:
+        A("ds_read_b128 v[%d:%d], v%d offset:%d" % (P0[p_next], P0[p_next] + 3, VP, p0_off))
     else:
         A("ds_read_b128 v[%d:%d], v%d" % (P0[p_next], P0[p_next] + 3, VP))
+    if advance:
+        A("v_add_u32 v%d, %d, v%d" % (VP, advance, VP))
 
 
 def body2(L, n, p, band):
     """Group k (phase p).  On entry: X(k), P0(k) were requested at the top of group k-1;
     s[HDR2] = row offset / 32 of group k+1, s[META_P[1-p]] bits 0..7 = accumulator of this group's
-    record 0 (left there by group k-1, or by the prologue)."""
+    record 0 (left there by group k-1, or by the prologue).  v[VP] is this group's payload address
+    in phase 0 and the PREVIOUS group's in phase 1: it moves once per two groups, by two strides
+    (both groups have the same stride, 32 bytes for more than 3 records, 16 otherwise -- where
+    the 32-byte groups end in phase 0, the bucket entry ESC2_E3_1 adds the difference)."""
     A = L.append
     stride = 32 if n > 3 else 16
     meta = META_P[p]
@@ -109,9 +108,11 @@ def body2(L, n, p, band):
     if "noprio" not in ABL:
         A("s_setprio %d" % (1 - p))
     A("s_set_gpr_idx_idx 0")
+    here = 0 if p == 0 else stride             # this group's payload relative to v[VP]
     if n > 3:
-        A("ds_read_b128 v[%d:%d], v%d offset:16" % (P1, P1 + 3, VP))
-    prefetch2(L, 1 - p, stride, band)          # group k+1: a whole group of FMAs to land in
+        A("ds_read_b128 v[%d:%d], v%d offset:%d" % (P1, P1 + 3, VP, here + 16))
+    # group k+1: a whole group of FMAs to land in
+    prefetch2(L, 1 - p, here + stride, 2 * stride if p == 1 else 0, band)
     if "noxp" in ABL:
         A("s_waitcnt lgkmcnt(%d)" % (2 if n > 3 else 1))
     else:
@@ -147,15 +148,15 @@ def generate2(band):
     L = []
     A = L.append
     A("s_waitcnt lgkmcnt(0)")
-    for n in range(1, MAX_SLOTS2 + 1):
-        A("s_mov_b32 s%d, %%[h%d]" % (END0 + n, 7 - n))
-    A("s_mov_b32 s%d, 0" % (END0 + MAX_SLOTS2 + 1))
-    A("s_cmp_eq_u32 s%d, 0" % (END0 + 1))
+    A("s_cmp_eq_u32 %%[h%d], 0" % 6)                      # END_1 = number of groups
     A("s_cbranch_scc1 ESC2_X_%=")
     A("s_mov_b32 s%d, %%[h0]" % META_P[1])                # plays the meta of "group -1"
     A(bfe(HDR2, META_P[1], 8, 11))                       # group 0
     A("v_mov_b32 v%d, %%[sbase]" % VP)
-    prefetch2(L, 0, 0, band)
+    prefetch2(L, 0, 0, 0, band)                          # ... its reads fly under the bookkeeping
+    for n in range(1, MAX_SLOTS2 + 1):
+        A("s_mov_b32 s%d, %%[h%d]" % (END0 + n, 7 - n))
+    A("s_mov_b32 s%d, 0" % (END0 + MAX_SLOTS2 + 1))
     A("s_lshr_b32 s%d, s%d, 21" % (HDR2, META_P[1]))     # group 1
     A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % META_P[1])
     A("s_branch ESC2_E%d_0_%%=" % MAX_SLOTS2)
@@ -163,6 +164,11 @@ def generate2(band):
         for p in (0, 1):
             # bucket n: groups [END_(n+1), END_n)
             A("ESC2_E%d_%d_%%=:" % (n, p))
+            if n == 3 and p == 1:
+                # the last 32-byte group ran in phase 0: v[VP] is its address, the 16-byte
+                # groups' phase 1 expects "previous group = 16 bytes back"
+                A("s_set_gpr_idx_idx 0")
+                A("v_add_u32 v%d, 16, v%d" % (VP, VP))
             A("s_sub_u32 s%d, s%d, s%d" % (CNT, END0 + n, END0 + n + 1))
             A("s_cmp_eq_u32 s%d, 0" % CNT)
             A("s_cbranch_scc1 ESC2_E%d_%d_%%=" % (n - 1, p))
