@@ -114,7 +114,9 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
       const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, passes, nseg);
       if (!t.ok || t.G < 1) continue;
       const double c = launch_cost_us(g, t, n_cu);
-      if (c < best_cost * 0.97) {      // a clear win only: ties keep fewer passes / fuller tiles
+      // more passes stage the input more often: only for a clear win; fewer images per tile at
+      // the same number of passes cost nothing (fewer, larger blocks): any win counts
+      if (c < best_cost * (passes > best.n_ocblk ? 0.97 : 0.999)) {
         best = t;
         best_cost = c;
       }
