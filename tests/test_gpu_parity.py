@@ -388,3 +388,36 @@ def test_randomised_tiled_geometries(pkg, oracle, synth, torch_cuda, seed):
         assert rel_err(got, want) <= TOL, "%s %s via %s: %g" % (s.name, (N, C, H, W, M, K, pad, group, sp), name, rel_err(got, want))
         checked += "tiled" in name
     assert checked >= 40      # nearly all of these must have gone down the tiled path
+
+
+def test_batches_beyond_one_buffer_descriptor(pkg, oracle, synth):
+    """The plane DMA addresses the input through a 32-bit buffer descriptor; larger batches are
+    served by consecutive sub-batch launches.  Run in a child process with the limit lowered to a
+    few images' worth of bytes so that the split is exercised on a small problem."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package(); oracle = ge.load_oracle(); synth = pkg.synth
+s = synth.shape("chunked", 11, 6, 9, 10, 8, 3, pad=1, sparsity=0.7)
+w, b, x = synth.pruned_weights(s, 1), synth.bias_vector(s, 2), synth.activations(s, 3)
+plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_TILED)
+plan.weight_align(w)
+dev = torch.device("cuda:0")
+top = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
+want = oracle.conv_forward(g, x, w, b, gate=False)
+err = float(np.abs(top - want).max() / max(1e-6, np.abs(want).max()))
+print("REL_ERR %%g" %% err)
+sys.exit(0 if err <= 1e-4 else 1)
+""" % root
+    env = dict(os.environ)
+    env["ESCOIN_MAX_BLOB_BYTES"] = str(3 * 6 * 9 * 10 * 4 + 100)      # three images per launch
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout.decode()
+    assert "REL_ERR" in out.stdout.decode()
