@@ -163,17 +163,19 @@ def main():
     torch.cuda.synchronize()
 
     def step(events=None):
+        # one HIP event between consecutive launches (the end of launch i is the start of launch
+        # i + 1): half the marker packets of a start/stop pair per launch, and a launch's duration
+        # then includes its dispatch gap, which is what the step pays for it
+        if events is not None:
+            events[0].record()
         for li, (s, plan, bias, si) in enumerate(layers):
-            if events is not None:
-                events[li][0].record()
             plan.forward(bottoms[si], bias, tops[si])
             if events is not None:
-                events[li][1].record()
+                events[li + 1].record()
 
     for _ in range(args.warmup):
         step()
-    ev = [[[torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-           for _ in layers] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(layers) + 1)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,7 +199,7 @@ def main():
     per_kernel = {}
     layer_ms = []
     for li, (s, plan, bias, si) in enumerate(layers):
-        ms = [ev[k][li][0].elapsed_time(ev[k][li][1]) for k in range(args.steps)]
+        ms = [ev[k][li].elapsed_time(ev[k][li + 1]) for k in range(args.steps)]
         m = float(np.mean(ms))
         layer_ms.append(m)
         d = per_kernel.setdefault(plan.kernel_name, {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0})

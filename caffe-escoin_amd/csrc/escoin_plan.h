@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "escoin.h"
+#include "stream_builder.h"
 
 namespace escoin {
 
@@ -49,6 +50,7 @@ struct TiledConfig {
   size_t lds_bytes = 0;
   int lds_budget = 0;  // plane-buffer budget the tiling was chosen with
   float density = 0.f; // nonzero fraction of the weights the tiling was chosen with
+  Tiling tiling;       // the tiling itself (chosen once in WeightAlign; launches only read it)
   int stage_bytes = 0; // LDS bytes of one wave's weight-stream staging area
 };
 
