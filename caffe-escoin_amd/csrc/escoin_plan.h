@@ -52,6 +52,7 @@ struct TiledConfig {
   float density = 0.f; // nonzero fraction of the weights the tiling was chosen with
   Tiling tiling;       // the tiling itself (chosen once in WeightAlign; launches only read it)
   int stage_bytes = 0; // LDS bytes of one wave's weight-stream staging area
+  int nbuf = 2;        // plane / staging buffers per workgroup
 };
 
 }  // namespace escoin
