@@ -24,7 +24,12 @@ def short(name):
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     os.makedirs("profiles", exist_ok=True)
-    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    # gpurun merges every run's files into the same local directory: take the newest of each kind
+    def newest(pattern):
+        files = glob.glob(pattern, recursive=True)
+        return [max(files, key=os.path.getmtime)] if files else []
+
+    stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open("profiles/%s_kernel_stats.csv" % tag, "w") as f:
@@ -36,8 +41,7 @@ def main():
                             r["Percentage"], r["MinNs"], r["MaxNs"]])
     out = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-        files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
-        for fn in files:
+        for fn in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
             for r in csv.DictReader(open(fn)):
                 k = short(r["Kernel_Name"])
                 if not k.startswith("escoin"):
