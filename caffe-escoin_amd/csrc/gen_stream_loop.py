@@ -51,6 +51,7 @@ END0 = 38                    # END_n in s[END0 + n], n = 1..6; s[END0 + 7] = 0
 SGPR_LAST = 45
 MAX_SLOTS2 = 6
 ABL = set()                  # timing-only ablations (see main())
+PRIO_HI = 1                  # priority of a wave's even groups (odd groups run at 0)
 
 
 def bfe(dst, src, off, width):
@@ -106,7 +107,7 @@ def body2(L, n, p, band):
     # slower all kernel long and every block waits for it.  Alternating priority by group parity
     # lets whichever wave is behind win its even groups.
     if "noprio" not in ABL:
-        A("s_setprio %d" % (1 - p))
+        A("s_setprio %d" % ((1 - p) * PRIO_HI))
     A("s_set_gpr_idx_idx 0")
     here = 0 if p == 0 else stride             # this group's payload relative to v[VP]
     if n > 3:
@@ -203,6 +204,8 @@ def main():
     import os
     if os.environ.get("ESC_GEN_NOPRIO"):
         ABL.add("noprio")
+    global PRIO_HI
+    PRIO_HI = int(os.environ.get("ESC_GEN_PRIO_HI", PRIO_HI))
     out = sys.stdout
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
