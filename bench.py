@@ -56,6 +56,7 @@ def cpu_baseline(oracle, synth, shapes, budget_s):
     cores = os.cpu_count() or 1
     use_ref = oracle.have_ref()
     per_image_s = 0.0
+    per_image_1t_s = 0.0      # as the reference's g++ build runs it: one thread, serial batch loop
     sample = []
     share = budget_s / max(1, len(shapes))
     for k, s in enumerate(shapes):
@@ -79,14 +80,24 @@ def cpu_baseline(oracle, synth, shapes, budget_s):
             run(x)
             t1 = time.perf_counter() - t0
         per_image_s += s.count * t1 / n
+        run1 = (lambda x: oracle.ref_conv_forward(g, x, w, b, threads=1)) if use_ref else \
+               (lambda x: oracle.conv_forward(g, x, w, b, threads=1, gate=False))
+        x1 = synth.activations(s, 3000 + k, 0, 2)
+        run1(x1[:1])
+        t0 = time.perf_counter()
+        run1(x1)
+        per_image_1t_s += s.count * (time.perf_counter() - t0) / 2
         sample.append("%s:%dimg" % (s.name, n))
         log("  cpu %-16s %6d img in %.3f s -> %.1f img/s/layer (%d threads)" %
             (s.name, n, t1, n / t1, cores))
     return {"value": round(1.0 / per_image_s, 3), "unit": "images/s", "cores": cores,
             "kind": "reference" if use_ref else "port",
+            "single_thread_value": round(1.0 / per_image_1t_s, 3),
             "sample": "whole-batch forward of " + ", ".join(sample) +
                       " per distinct layer shape, OpenMP over images; per-image time summed "
-                      "over all %d layers" % sum(s.count for s in shapes)}
+                      "over all %d layers; single_thread_value = the same on one thread (2 images "
+                      "per shape), the way the reference's g++ build runs its batch loop"
+                      % sum(s.count for s in shapes)}
 
 
 def main():
