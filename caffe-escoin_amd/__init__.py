@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ESCOIN_LIB") or os.path.join(_HERE, "libescoin_hip.so")
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED, KERNEL_DENSE = 0, 1, 2, 3
-CONV_MODE_LOWERED_SPARSE, CONV_MODE_SCONV, CONV_MODE_SCONV_PAR = 1, 2, 3
+CONV_MODE_LOWERED_GEMM, CONV_MODE_LOWERED_SPARSE, CONV_MODE_SCONV, CONV_MODE_SCONV_PAR = 0, 1, 2, 3
 
 # every symbol include/escoin.h declares (tests check the library exports all of them)
 API_SYMBOLS = [
@@ -138,7 +138,7 @@ def _np_ptr(a):
 class Plan(object):
     """escoin_plan: one ConvolutionLayer's sparse state (CSR + weight streams) on one device."""
 
-    def __init__(self, desc, kernel=KERNEL_AUTO, conv_mode=CONV_MODE_SCONV_PAR):
+    def __init__(self, desc, kernel=KERNEL_AUTO, conv_mode=CONV_MODE_SCONV_PAR, **options):
         self.desc = desc
         self._h = C.c_void_p()
         check(lib().escoin_plan_create(C.byref(desc), C.byref(self._h)), "escoin_plan_create")
@@ -146,6 +146,8 @@ class Plan(object):
             self.set_option("kernel", kernel)
         if conv_mode != CONV_MODE_SCONV_PAR:
             self.set_option("conv_mode", conv_mode)
+        for k, v in options.items():      # e.g. tiling_batch=256, dense_gate=1, dense_threshold_pct=30
+            self.set_option(k, v)
         self.out_hw = out_shape(desc)
 
     def close(self):

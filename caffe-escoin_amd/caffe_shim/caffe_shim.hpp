@@ -302,23 +302,29 @@ class BaseConvolutionLayer : public Layer<Dtype> {   // base_conv_layer.hpp:20-2
     same_but_n.N = plan_ ? desc_.N : d.N;
     const bool reusable = plan_ && d.N <= desc_.N && memcmp(&same_but_n, &desc_, sizeof(d)) == 0;
     if (!reusable) {
-      // geometry changed (or first call): new plan; keeps the CSR if it was already aligned
+      // geometry changed, batch grew past the planned one, or first call: a fresh plan.  The
+      // reference's Reshape leaves the CSR blobs alone (they depend on the weights only) but its
+      // stretched indices and padded buffer go stale until the next WeightAlign; here a layer
+      // that was aligned is re-aligned from blobs_[0] on the spot, so Forward keeps working.
       escoin_plan *fresh = nullptr;
       ESCOIN_CHECK(escoin_plan_create(&d, &fresh));
       if (plan_) escoin_plan_destroy(plan_);
       plan_ = fresh;
       desc_ = d;
+      const bool was_aligned = aligned_;
       aligned_ = false;
+      if (was_aligned) WeightAlign();
     }
   }
 
   // base_conv_layer.cpp:46-273: dense blobs_[0] -> CSR (+ the device weight streams), once
   virtual void WeightAlign() {
     ESC_CHECK(plan_ != nullptr);   // SetUp must have run
-    ESC_CHECK(Caffe::conv_mode() == Caffe::SCONV || Caffe::conv_mode() == Caffe::SCONV_PAR);
-    ESCOIN_CHECK(escoin_plan_set_option(plan_, "conv_mode",
-                                        Caffe::conv_mode() == Caffe::SCONV ? ESCOIN_CONV_MODE_SCONV
-                                                                           : ESCOIN_CONV_MODE_SCONV_PAR));
+    // Caffe::ConvMode and ESCOIN_CONV_MODE_* share their values (common.hpp:112).  The reference's
+    // WeightAlign only builds the CSR for the sparse modes and leaves LOWERED_GEMM alone
+    // (base_conv_layer.cpp:49-53); here every mode is served from the aligned plan.
+    ESCOIN_CHECK(escoin_plan_set_option(plan_, "conv_mode", (int)Caffe::conv_mode()));
+    aligned_mode_ = Caffe::conv_mode();
     if (Caffe::mode() == Caffe::GPU)
       ESCOIN_CHECK(escoin_weight_align(plan_, this->blobs_[0]->gpu_data(), 1, Caffe::stream()));
     else
@@ -345,12 +351,17 @@ class BaseConvolutionLayer : public Layer<Dtype> {   // base_conv_layer.hpp:20-2
   // forward_gpu_sconv_par + forward_gpu_bias (base_conv_layer.cpp:800-856) for the whole batch
   void forward_gpu_sconv_par(const Dtype *input, const Dtype * /*weights*/, Dtype *output) {
     ESC_CHECK(aligned_);   // the reference silently computes zeros here
+    if (Caffe::conv_mode() != aligned_mode_) {   // `caffe test -conv_mode N` flipped after the load
+      ESCOIN_CHECK(escoin_plan_set_option(plan_, "conv_mode", (int)Caffe::conv_mode()));
+      aligned_mode_ = Caffe::conv_mode();
+    }
     const Dtype *bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
     ESCOIN_CHECK(escoin_forward(plan_, input, bias, output, num_, Caffe::stream()));
   }
   escoin_plan *plan_;
   escoin_conv_desc desc_;
   bool aligned_ = false;
+  Caffe::ConvMode aligned_mode_ = Caffe::SCONV_PAR;
   int num_, channels_, group_, num_output_;
   bool bias_term_, fuse_relu_;
   int planned_num_;
@@ -370,7 +381,6 @@ class ConvolutionLayer : public BaseConvolutionLayer<Dtype> {   // conv_layer.hp
   // conv_layer.cu:8-40.  SCONV and SCONV_PAR produce the same numbers; both go through one
   // batched launch per bottom (the per-image launches of SCONV are a reference artefact).
   virtual void Forward_gpu(const vector<Blob<Dtype> *> &bottom, const vector<Blob<Dtype> *> &top) {
-    ESC_CHECK(Caffe::conv_mode() == Caffe::SCONV || Caffe::conv_mode() == Caffe::SCONV_PAR);
     const Dtype *weight = this->blobs_[0]->gpu_data();
     for (size_t i = 0; i < bottom.size(); ++i) {
       const Dtype *bottom_data = bottom[i]->gpu_data();
@@ -387,6 +397,26 @@ class ConvolutionReLULayer : public ConvolutionLayer<Dtype> {   // conv_relu_lay
     this->fuse_relu_ = true;
   }
   virtual inline const char *type() const { return "ConvolutionReLU"; }
+};
+
+// layer_factory.hpp:53-110 / layer_factory.cpp:74: the creator registry `Net::Init` looks layer
+// types up in (LayerRegistry<Dtype>::CreateLayer(param)), with the two creators this path owns.
+template <typename Dtype>
+class LayerRegistry {
+ public:
+  typedef shared_ptr<Layer<Dtype> > (*Creator)(const LayerParameter &);
+  static shared_ptr<Layer<Dtype> > CreateLayer(const LayerParameter &param) {
+    if (param.type == "Convolution") return shared_ptr<Layer<Dtype> >(new ConvolutionLayer<Dtype>(param));
+    if (param.type == "ConvolutionReLU") return shared_ptr<Layer<Dtype> >(new ConvolutionReLULayer<Dtype>(param));
+    fprintf(stderr, "Unknown layer type: %s (known types: Convolution, ConvolutionReLU)\n", param.type.c_str());
+    abort();   // LOG(FATAL), layer_factory.hpp:79-80
+  }
+  static vector<string> LayerTypeList() {
+    vector<string> v;
+    v.push_back("Convolution");
+    v.push_back("ConvolutionReLU");
+    return v;
+  }
 };
 
 }  // namespace caffe

@@ -32,6 +32,7 @@ struct DenseArgs {
   int n_images, C, H, W, M, OH, OW, KH, KW;
   int pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
   int Cg, Mg, K, P, relu;
+  unsigned long long group_mask;   // conv groups this launch covers (all ones: every group)
 };
 
 template <int WROWS>
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(256) escoin_dense_mfma_kernel(DenseArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WCOLS, wn = wave % WCOLS;
-  const int cg = blockIdx.z;
+  const int cg = a.group_mask == ~0ull ? (int)blockIdx.z : nth_set_bit(a.group_mask, blockIdx.z);
   const int m0 = blockIdx.y * BM;                   // first output channel (group-local)
   const int p0 = blockIdx.x * kBN;                  // first flattened output pixel
   const int khw = a.KH * a.KW;
@@ -181,7 +182,9 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   if (P >= (1l << 31)) return fail(ESCOIN_EINVAL, "dense kernel: N*OH*OW does not fit 31 bits");
   a.P = (int)P;
   const int bm = g.Mg <= 64 ? 64 : 128;
-  dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((g.Mg + bm - 1) / bm), (unsigned)g.d.group);
+  a.group_mask = p->use_dense ? ~0ull : p->dense_mask;
+  dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((g.Mg + bm - 1) / bm),
+            (unsigned)(p->use_dense ? g.d.group : p->n_dense_groups));
   if (grid.y > 65535u || grid.z > 65535u) return fail(ESCOIN_EINVAL, "dense kernel: grid too large");
   if (bm == 64) hipLaunchKernelGGL(escoin_dense_mfma_kernel<1>, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(escoin_dense_mfma_kernel<2>, grid, dim3(256), 0, stream, a);

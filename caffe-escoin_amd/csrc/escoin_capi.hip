@@ -20,6 +20,10 @@ int fail(int code, const std::string &msg) {
   return code;
 }
 
+// Density above which KERNEL_AUTO sends a conv group to the dense fp32-MFMA kernel: the measured
+// crossover between the tiled sparse kernel and the dense kernel (profiles/r02_crossover.md).
+constexpr int kDefaultDenseThresholdPct = 60;
+
 static int out_dim(int in, int k, int pad, int stride, int dil) {
   // conv_layer.cpp:16-19
   return (in + 2 * pad - (dil * (k - 1) + 1)) / stride + 1;
@@ -108,22 +112,53 @@ static int upload(escoin_plan *p, hipStream_t stream) {
   ESCOIN_HIP_TRY(hipStreamSynchronize(stream));  // host vectors die at scope exit
 
   p->tiled = TiledConfig();
-  // dense path: asked for explicitly, or through the reference's gate on group 0's density
-  // (nz_num_[0] / (M/g * kernel_dim) > 0.2, base_conv_layer.cpp:750, :805)
-  const double density0 = (double)p->colidx[0].size() / ((double)g.Mg * g.kdim);
-  p->use_dense = p->kernel_choice == ESCOIN_KERNEL_DENSE ||
-                 (p->kernel_choice == ESCOIN_KERNEL_AUTO && p->dense_gate && density0 > 0.2);
-  if (p->use_dense) {
-    std::vector<float> dense((size_t)g.d.M * g.kdim, 0.f);
-    for (int grp = 0; grp < g.d.group; ++grp)
+  // ---- which conv groups go to the dense (fp32 MFMA) kernel -------------------------------
+  //  * kernel DENSE or conv_mode LOWERED_GEMM (forward_gpu_gemm, base_conv_layer.cpp:713-746): all;
+  //  * dense_gate = 1: the reference's gate -- group 0's density decides for the whole layer
+  //    (nz_num_[0] / (M/g * kernel_dim) > 0.2, base_conv_layer.cpp:750, :805; quirk 5);
+  //  * otherwise (AUTO): each group by its own density against the measured crossover
+  //    (profiles/r02_crossover.md; option "dense_threshold_pct" overrides).
+  const int G = g.d.group;
+  std::vector<char> dense(G, 0);
+  const double per_group = (double)g.Mg * g.kdim;
+  if (p->kernel_choice == ESCOIN_KERNEL_DENSE || p->conv_mode == ESCOIN_CONV_MODE_LOWERED_GEMM) {
+    dense.assign(G, 1);
+  } else if (p->kernel_choice == ESCOIN_KERNEL_AUTO) {
+    if (p->dense_gate) {
+      if ((double)p->colidx[0].size() / per_group > 0.2) dense.assign(G, 1);
+    } else {
+      const double thr = (p->dense_threshold_pct >= 0 ? p->dense_threshold_pct : kDefaultDenseThresholdPct) / 100.0;
+      if (G <= 64) {
+        for (int grp = 0; grp < G; ++grp) dense[grp] = (double)p->colidx[grp].size() / per_group > thr;
+      } else if ((double)nnz / (per_group * G) > thr) {
+        dense.assign(G, 1);
+      }
+    }
+  }
+  p->n_dense_groups = 0;
+  p->dense_mask = 0;
+  for (int grp = 0; grp < G; ++grp)
+    if (dense[grp]) {
+      ++p->n_dense_groups;
+      if (grp < 64) p->dense_mask |= 1ull << grp;
+    }
+  p->n_sparse_groups = G - p->n_dense_groups;
+  p->use_dense = p->n_dense_groups == G;
+  if (p->use_dense) p->dense_mask = ~0ull;
+  p->sparse_mask = p->n_dense_groups == 0 ? ~0ull : ~p->dense_mask & (G >= 64 ? ~0ull : ((1ull << G) - 1));
+  if (p->n_dense_groups > 0) {
+    std::vector<float> dw((size_t)g.d.M * g.kdim, 0.f);
+    for (int grp = 0; grp < G; ++grp)
       for (int m = 0; m < g.Mg; ++m)
         for (int j = p->rowptr[grp][m]; j < p->rowptr[grp][m + 1]; ++j)
-          dense[((size_t)grp * g.Mg + m) * g.kdim + p->colidx[grp][j]] = p->values[grp][j];
-    ESCOIN_HIP_TRY(hipMalloc(&p->d_dense_w, sizeof(float) * dense.size()));
-    p->device_bytes += sizeof(float) * dense.size();
-    ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_dense_w, dense.data(), sizeof(float) * dense.size(),
+          dw[((size_t)grp * g.Mg + m) * g.kdim + p->colidx[grp][j]] = p->values[grp][j];
+    ESCOIN_HIP_TRY(hipMalloc(&p->d_dense_w, sizeof(float) * dw.size()));
+    p->device_bytes += sizeof(float) * dw.size();
+    ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_dense_w, dw.data(), sizeof(float) * dw.size(),
                                   hipMemcpyHostToDevice, stream));
     ESCOIN_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  if (p->use_dense) {
     p->kernel_name = dense_kernel_name();
     p->aligned = true;
     return ESCOIN_OK;
@@ -139,6 +174,7 @@ static int upload(escoin_plan *p, hipStream_t stream) {
       return fail(ESCOIN_EINVAL, "tiled kernel requested but its weight stream does not fit the LDS budget");
   }
   p->kernel_name = p->tiled.enabled ? tiled_kernel_name(p) : generic_kernel_name(g.d.fuse_relu != 0);
+  if (p->n_dense_groups > 0) p->kernel_name += std::string(" + ") + dense_kernel_name();
   p->aligned = true;
   return ESCOIN_OK;
 }
@@ -199,16 +235,29 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
   if (!p || !key) return fail(ESCOIN_EINVAL, "null argument");
   if (p->aligned && strcmp(key, "conv_mode") != 0)
     return fail(ESCOIN_ESTATE, "this option must be set before weight_align/set_csr");
+  if (!strcmp(key, "tiling_batch")) {
+    if (value < 0) return fail(ESCOIN_EINVAL, "tiling_batch must be >= 0");
+    p->tiling_batch = value;
+    return ESCOIN_OK;
+  }
+  if (!strcmp(key, "dense_threshold_pct")) {
+    if (value < -1 || value > 100) return fail(ESCOIN_EINVAL, "dense_threshold_pct must be in [-1, 100]");
+    p->dense_threshold_pct = value;
+    return ESCOIN_OK;
+  }
   if (!strcmp(key, "kernel")) {
     if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_DENSE)
       return fail(ESCOIN_EINVAL, "unknown kernel id");
     p->kernel_choice = value;
   } else if (!strcmp(key, "conv_mode")) {
-    if (value != ESCOIN_CONV_MODE_SCONV && value != ESCOIN_CONV_MODE_SCONV_PAR &&
-        value != ESCOIN_CONV_MODE_LOWERED_SPARSE)
-      return fail(ESCOIN_EINVAL, "conv_mode must be SCONV (2), SCONV_PAR (3) or the LOWERED_SPARSE (1) "
-                                 "comparator; LOWERED_GEMM (0) is the kernel option ESCOIN_KERNEL_DENSE");
+    if (value < ESCOIN_CONV_MODE_LOWERED_GEMM || value > ESCOIN_CONV_MODE_SCONV_PAR)
+      return fail(ESCOIN_EINVAL, "conv_mode must be one of Caffe::ConvMode's four values (0..3)");
+    const bool regroup = p->aligned && (value == ESCOIN_CONV_MODE_LOWERED_GEMM) !=
+                                           (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_GEMM);
     p->conv_mode = value;
+    // to or from LOWERED_GEMM on an aligned plan: the dense / sparse device structures are rebuilt
+    // from the CSR the plan holds (the other three modes share theirs)
+    if (regroup) return upload(p, nullptr);
   } else if (!strcmp(key, "dense_gate")) {
     p->dense_gate = value != 0;
   } else {
@@ -332,7 +381,10 @@ int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_de
   hipStream_t s = (hipStream_t)stream;
   if (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && !p->use_dense)
     return launch_lowered(p, bottom_dev, bias_dev, top_dev, n_images, s);
-  if (p->use_dense) return launch_dense(p, bottom_dev, bias_dev, top_dev, n_images, s);
+  if (p->n_dense_groups > 0) {
+    const int rc = launch_dense(p, bottom_dev, bias_dev, top_dev, n_images, s);
+    if (rc != ESCOIN_OK || p->use_dense) return rc;
+  }
   if (p->tiled.enabled) return launch_tiled(p, bottom_dev, bias_dev, top_dev, n_images, s);
   return launch_generic(p, bottom_dev, bias_dev, top_dev, n_images, s);
 }

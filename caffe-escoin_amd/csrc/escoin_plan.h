@@ -62,6 +62,7 @@ struct escoin_plan {
   int kernel_choice = ESCOIN_KERNEL_AUTO;
   int conv_mode = ESCOIN_CONV_MODE_SCONV_PAR;
   int dense_gate = 0;
+  int tiling_batch = 0;   // option "tiling_batch": choose the tiled kernel's tiling as for this batch (0: desc.N)
   bool aligned = false;
   int device = -1;
 
@@ -82,9 +83,14 @@ struct escoin_plan {
   unsigned *d_unit_hdr = nullptr; // 8 dwords per (conv group, oc group, ic block)
   size_t stream_words = 0;
 
-  // dense fallback (fp32 MFMA implicit GEMM)
+  // dense fallback (fp32 MFMA implicit GEMM), chosen per conv group: bit g of dense_mask = group g
+  // goes to the MFMA kernel, bit g of sparse_mask = to the sparse kernels (layers with more than 64
+  // groups take one decision for all of them: both masks are then all-ones / zero)
   float *d_dense_w = nullptr;     // [M][Cg*KH*KW]
-  bool use_dense = false;
+  bool use_dense = false;         // every group dense
+  unsigned long long dense_mask = 0, sparse_mask = ~0ull;
+  int n_dense_groups = 0, n_sparse_groups = 0;
+  int dense_threshold_pct = -1;   // option "dense_threshold_pct" (-1: the measured default)
 
   // LOWERED_SPARSE comparator (sconv_lowered.hip): column buffer, grown on demand
   float *d_col = nullptr;
@@ -119,6 +125,15 @@ const char *lowered_kernel_name();
 int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, float *top,
                  int n_images, hipStream_t stream);
 const char *dense_kernel_name();
+
+// Index of the k-th set bit of `mask` (k < popcount): blockIdx -> conv group when only some groups
+// of a layer run in a launch.  Wave-uniform scalar code on the device.
+__host__ __device__ inline int nth_set_bit(unsigned long long mask, int k) {
+  for (; k > 0; --k) mask &= mask - 1;
+  int i = 0;
+  while (i < 63 && !((mask >> i) & 1ull)) ++i;
+  return i;
+}
 
 }  // namespace escoin
 

@@ -35,6 +35,7 @@ struct GenericArgs {
   int C, H, W, M, OH, OW;
   int pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
   int Cg, Mg;
+  unsigned long long group_mask;   // conv groups this launch covers (the others: MFMA kernel)
 };
 
 template <bool RELU>
@@ -52,6 +53,7 @@ escoin_sconv_generic_kernel(GenericArgs a) {
   const int ih0 = oh * a.stride_h - a.pad_h;
   const int iw0 = ow * a.stride_w - a.pad_w;
   const int grp = oc / a.Mg;
+  if (a.group_mask != ~0ull && !((a.group_mask >> grp) & 1ull)) return;   // wave-uniform
   const float *__restrict__ img = a.in + ((size_t)n * a.C + (size_t)grp * a.Cg) * a.H * a.W;
   const int jb = a.rowptr[oc], je = a.rowptr[oc + 1];
   float sum = 0.f;
@@ -88,6 +90,7 @@ int launch_generic(const escoin_plan *p, const float *bottom, const float *bias,
   a.C = g.d.C; a.H = g.d.H; a.W = g.d.W; a.M = g.d.M; a.OH = g.OH; a.OW = g.OW;
   a.pad_h = g.d.pad_h; a.pad_w = g.d.pad_w; a.stride_h = g.d.stride_h; a.stride_w = g.d.stride_w;
   a.dil_h = g.d.dil_h; a.dil_w = g.d.dil_w; a.Cg = g.Cg; a.Mg = g.Mg;
+  a.group_mask = p->n_dense_groups > 0 ? p->sparse_mask : ~0ull;
   const int npix = g.OH * g.OW;
   dim3 block(64, kWavesPerBlock, 1);
   dim3 grid((npix + 63) / 64, (g.d.M + kWavesPerBlock - 1) / kWavesPerBlock, n_images);

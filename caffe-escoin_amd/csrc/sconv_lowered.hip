@@ -137,10 +137,14 @@ int launch_lowered(escoin_plan *p, const float *bottom, const float *bias, float
     chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_images, kColBytes / per_image));
     const size_t need = per_image * chunk;
     if (p->col_bytes < need) {
+      // the plan never holds a size for a buffer it no longer has: a failed hipMalloc leaves
+      // d_col = nullptr AND col_bytes = 0, so a later, smaller forward allocates again
       if (p->d_col) (void)hipFree(p->d_col);
       p->d_col = nullptr;
+      p->device_bytes -= p->col_bytes;
+      p->col_bytes = 0;
       ESCOIN_HIP_TRY(hipMalloc(&p->d_col, need));
-      p->device_bytes += need - p->col_bytes;
+      p->device_bytes += need;
       p->col_bytes = need;
     }
   }

@@ -65,6 +65,8 @@ Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int 
   t.plane_seg_floats = t.plane_rows * t.RS;
   t.plane_ch_floats = t.nseg * t.plane_seg_floats;
   const int per_ch = t.plane_ch_floats * 4;
+  // (row offsets travel as offset / 32 in 11-bit fields of the stream: 64 KiB per plane buffer)
+  lds_budget_bytes = std::min(lds_budget_bytes, 64 * 1024);
   int icb = lds_budget_bytes / per_ch;
   if (icb < 1) return t;                       // one channel does not fit
   icb = std::min(icb, g.Cg);
@@ -225,7 +227,11 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
         const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
         uint32_t *hdr = &ws.unit_hdr[ui * kUnitHdrDwords];
         const int tg = (int)groups.size();
-        auto row32 = [&](int k) -> uint32_t { return k < tg ? groups[k].lds_off / 32u : 0u; };
+        auto row32 = [&](int k) -> uint32_t {
+          const uint32_t r = k < tg ? groups[k].lds_off / 32u : 0u;
+          if (r >= 2048u) ws.overflow = true;   // does not fit the 11-bit field: the caller rejects the tiling
+          return r;
+        };
         auto first = [&](int k) -> uint32_t { return k < tg ? 4u * groups[k].recs[0].idx : 0u; };
         hdr[0] = first(0) | (row32(0) << 8) | (row32(1) << 21);
         for (int n = kMaxSlots; n >= 1; --n) {

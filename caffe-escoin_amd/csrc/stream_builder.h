@@ -96,6 +96,7 @@ struct WeightStream {
   std::vector<uint32_t> unit_hdr;   // [group][n_ocg][n_icb][8]
   int max_body_bytes = 0;
   long n_groups = 0, n_records = 0;
+  bool overflow = false;            // an LDS row offset did not fit its field (plane buffer > 64 KiB)
 };
 
 WeightStream build_stream(const ConvGeom &g, const Tiling &t,

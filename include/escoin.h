@@ -51,9 +51,9 @@ extern "C" {
 #define ESCOIN_ESTATE (-4)    /* forward before weight_align / set_csr          */
 #define ESCOIN_ENODEVICE (-5) /* no HIP device visible                          */
 
-/* Caffe::ConvMode, include/caffe/common.hpp:112.  Only the two direct-sparse modes are
- * served by this library; they differ in the reference only by launch granularity
- * (per image vs whole batch, conv_layer.cu:16-26) and produce the same numbers. */
+/* Caffe::ConvMode, include/caffe/common.hpp:112.  The two direct-sparse modes differ in the
+ * reference only by launch granularity (per image vs whole batch, conv_layer.cu:16-26) and produce
+ * the same numbers; LOWERED_GEMM is the dense MFMA kernel, LOWERED_SPARSE the lowering comparator. */
 #define ESCOIN_CONV_MODE_LOWERED_GEMM 0
 #define ESCOIN_CONV_MODE_LOWERED_SPARSE 1
 #define ESCOIN_CONV_MODE_SCONV 2
@@ -100,13 +100,23 @@ ESCOIN_API long escoin_padded_len(const escoin_conv_desc *desc);
 ESCOIN_API int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan);
 ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
 
-/* Options: "kernel" = ESCOIN_KERNEL_*, "conv_mode" = ESCOIN_CONV_MODE_SCONV / SCONV_PAR (the
- * direct path; the two differ only in the reference's batching) or LOWERED_SPARSE (comparator:
- * im2col + CSR x dense per image, base_conv_layer.cpp:724-736; may be switched after align),
- * "dense_gate" = 0/1 (1: reproduce the reference's per-layer gate that sends
- * density(group 0) > 0.2 to the dense GEMM path, base_conv_layer.cpp:750-755,805-811;
- * here the dense path is the fp32-MFMA implicit-GEMM kernel, ESCOIN_KERNEL_DENSE).
- * "kernel" and "dense_gate" must precede weight_align. */
+/* Options (all but "conv_mode" must precede weight_align / set_csr):
+ *   "kernel"     = ESCOIN_KERNEL_*;
+ *   "conv_mode"  = Caffe::ConvMode (common.hpp:112; tools/caffe.cpp:292-301 -conv_mode N):
+ *                  SCONV / SCONV_PAR = the direct sparse path (the two differ only in the
+ *                  reference's batching), LOWERED_SPARSE = the comparator (im2col + CSR x dense per
+ *                  image, base_conv_layer.cpp:724-736), LOWERED_GEMM = every group on the dense
+ *                  fp32-MFMA implicit-GEMM kernel (forward_gpu_gemm, base_conv_layer.cpp:713-746).
+ *                  May be switched on an aligned plan;
+ *   "dense_gate" = 0/1.  0 (default): KERNEL_AUTO sends EACH conv group whose own density exceeds
+ *                  the measured sparse/dense crossover to the MFMA kernel and the others to the
+ *                  sparse kernel.  1: reproduce the reference's gate -- density(group 0) > 0.2
+ *                  sends the whole layer to the dense path (base_conv_layer.cpp:750-755,805-811);
+ *   "dense_threshold_pct" = density in percent above which AUTO picks the dense kernel
+ *                  (-1 = the built-in measured crossover; 100 = never);
+ *   "tiling_batch" = choose the tiled kernel's tiling as for a batch of this many images
+ *                  (0 = desc.N).  Results do not depend on it; tests use it to run small inputs
+ *                  through the weight stream / tile shapes of the full-size configurations. */
 ESCOIN_API int escoin_plan_set_option(escoin_plan *plan, const char *key, int value);
 
 /* WeightAlign(): dense blobs_[0] (M x C/g x KH x KW, zeros = pruned) -> per-group CSR

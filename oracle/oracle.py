@@ -84,6 +84,21 @@ def ref():
             [_ip, _ip, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int]
         R.ref_conv_forward.restype = C.c_int
         R.ref_conv_forward.argtypes = [C.POINTER(Geom), C.c_int, _fp, _fp, C.c_void_p, _fp, C.c_int]
+        if hasattr(R, "ref_plan_create"):
+            R.ref_blocked_supported.restype = C.c_int
+            R.ref_blocked_supported.argtypes = [C.POINTER(Geom)]
+            R.ref_plan_create.restype = C.c_void_p
+            R.ref_plan_create.argtypes = [C.POINTER(Geom), _fp]
+            R.ref_plan_destroy.restype = None
+            R.ref_plan_destroy.argtypes = [C.c_void_p]
+            R.ref_plan_has_blocked.restype = C.c_int
+            R.ref_plan_has_blocked.argtypes = [C.c_void_p]
+            R.ref_plan_ncolblocks.restype = C.c_int
+            R.ref_plan_ncolblocks.argtypes = [C.c_void_p]
+            R.ref_plan_forward.restype = C.c_int
+            R.ref_plan_forward.argtypes = [C.c_void_p, C.c_int, _fp, C.c_void_p, _fp, C.c_int, C.c_int]
+            R.ref_thread_partition.restype = None
+            R.ref_thread_partition.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _ip]
         _ref = R
     return _ref
 
@@ -177,3 +192,65 @@ def ref_conv_forward(g, bottom, weights, bias=None, threads=1):
     if rc != 0:
         raise MemoryError("ref_conv_forward failed")
     return top
+
+
+class RefPlan(object):
+    """The reference CPU layer after WeightAlign (oracle/_ref): CSR (and, where the reference's
+    switchboard has an instantiation, the column-blocked CSR of its register-blocked kernel) built
+    once, so that forward() times only what the reference's Forward_cpu does per call.
+
+    kernel "default" = caffe_cpu_sconv's loop nest (math_functions.cpp:128-176), OpenMP over the
+    batch; kernel "blocked" = sconv_unit_stride (sconv.hpp:57-589) behind the reference's thread
+    grouping (cpu_info.cpp:483-605)."""
+
+    def __init__(self, g, weights):
+        self.g = g
+        self._w = np.ascontiguousarray(weights, np.float32)
+        self._h = ref().ref_plan_create(C.byref(g), self._w.ravel())
+        if not self._h:
+            raise MemoryError("ref_plan_create failed")
+
+    @property
+    def has_blocked(self):
+        return bool(ref().ref_plan_has_blocked(self._h))
+
+    @property
+    def ncolblocks(self):
+        return ref().ref_plan_ncolblocks(self._h)
+
+    def forward(self, bottom, bias=None, threads=1, kernel="default", top=None):
+        bottom = np.ascontiguousarray(bottom, np.float32)
+        N = bottom.shape[0]
+        oh, ow = out_hw(self.g)
+        if top is None:
+            top = np.zeros((N, self.g.M, oh, ow), np.float32)
+        keep, bp = _bias_ptr(bias)
+        rc = ref().ref_plan_forward(self._h, N, bottom.ravel(), bp, top.ravel(), int(threads),
+                                    1 if kernel == "blocked" else 0)
+        if rc != 0:
+            raise RuntimeError("ref_plan_forward failed (%d)" % rc)
+        return top
+
+    def close(self):
+        if self._h:
+            ref().ref_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def have_ref_plan():
+    return have_ref() and hasattr(ref(), "ref_plan_create")
+
+
+def thread_partition(n_threads, batch, work):
+    """The reference's thread grouping (cpu_info.cpp:483-540) for a team of n_threads: per thread
+    its group id, its group's [begin, end) of the batch and its own [begin, end) of `work`."""
+    z = lambda: np.zeros(n_threads, np.int32)
+    gid, bb, be, wb, we = z(), z(), z(), z(), z()
+    ref().ref_thread_partition(n_threads, batch, work, gid, bb, be, wb, we)
+    return gid, bb, be, wb, we

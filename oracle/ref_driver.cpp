@@ -39,6 +39,7 @@ unsigned long long conv_cycles_of_this_batch[1024 * 16], transpose_cycle, pool_c
 int flop_cnt;
 
 #include "sconv_oracle.h"
+#include "ref_plan.h"
 
 extern "C" {
 
@@ -112,6 +113,54 @@ int ref_conv_forward(const oracle_conv_geom *g, int N, const float *bottom,
             in_temp, Cg, g->H, g->W, g->pad_h, g->pad_w, g->stride_h, g->stride_w, g->dil_h,
             g->dil_w, rowptr.data() + row_offset * grp, colidx.data() + weight_offset * grp,
             values.data() + weight_offset * grp, g->KH, g->KW, zero_bias.data(),
+            out + (long)Mg * OH * OW * grp, Mg);
+      }
+      if (bias) oracle_bias(out, bias, g->M, OH * OW);
+    }
+    free(input_padded);
+  }
+  return rc;
+}
+
+/* The same forward from an aligned ref_plan (ref_blocked.cpp: ref_plan_create): the CSR was built
+ * once, as the reference's WeightAlign does; only the per-image work is left in the call. */
+int ref_plan_forward_default(const ref_plan *p, int N, const float *bottom, const float *bias, float *top,
+                             int n_threads) {
+  const oracle_conv_geom *g = &p->g;
+  const int group = g->group, Cg = p->Cg, Mg = p->Mg, OH = p->OH, OW = p->OW;
+  const long bottom_dim = (long)g->C * g->H * g->W, top_dim = (long)g->M * OH * OW;
+  const long weight_offset = (long)Mg * p->kdim;
+  const int row_offset = Mg + 1;
+  std::vector<float> zero_bias(g->M, 0.f);
+  const bool padded = g->pad_h != 0 || g->pad_w != 0;
+  if (n_threads < 1) n_threads = 1;
+  int rc = 0;
+#pragma omp parallel num_threads(n_threads)
+  {
+    float *input_padded = NULL;
+    if (padded) {
+      input_padded = (float *)calloc(p->plen, sizeof(float));
+      if (!input_padded) {
+#pragma omp atomic write
+        rc = -1;
+      }
+    }
+#pragma omp for schedule(static)
+    for (int n = 0; n < N; ++n) {
+      if (rc != 0) continue;
+      const float *image = bottom + n * bottom_dim;
+      float *out = top + n * top_dim;
+      const float *in_p = image;
+      if (padded) {
+        oracle_pad_input(g, image, input_padded);
+        in_p = input_padded;
+      }
+      for (int grp = 0; grp < group; ++grp) {
+        const float *in_temp = in_p + (long)Cg * grp * (g->H + g->pad_h) * (g->W + g->pad_w);
+        caffe_cpu_sconv_default<false>(
+            in_temp, Cg, g->H, g->W, g->pad_h, g->pad_w, g->stride_h, g->stride_w, g->dil_h,
+            g->dil_w, p->rowptr.data() + row_offset * grp, p->colidx.data() + weight_offset * grp,
+            p->values.data() + weight_offset * grp, g->KH, g->KW, zero_bias.data(),
             out + (long)Mg * OH * OW * grp, Mg);
       }
       if (bias) oracle_bias(out, bias, g->M, OH * OW);

@@ -96,6 +96,55 @@ static int run_case(const char *name, int N, int C, int H, int W, ConvolutionPar
   return ok ? 0 : 1;
 }
 
+// The Forward wrapper reshapes on every call (layer.hpp:436): a net that was WeightAlign'ed and is
+// then fed a larger batch, or another H x W, must keep producing the right numbers; so must a
+// `-conv_mode` flip after the weights were loaded, and a layer made through the registry.
+static int reshape_case() {
+  LayerParameter lp;
+  lp.name = "reshape";
+  lp.type = "Convolution";
+  lp.convolution_param.num_output = 12; lp.convolution_param.kernel_h = lp.convolution_param.kernel_w = 3;
+  lp.convolution_param.pad_h = lp.convolution_param.pad_w = 1;
+  const ConvolutionParameter cp = lp.convolution_param;
+  shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);   // layer_factory.cpp:74
+  Blob<float> b0(2, 8, 10, 10), t0;
+  std::vector<Blob<float> *> bottom(1, &b0), top(1, &t0);
+  layer->SetUp(bottom, top);
+  std::vector<float> w(layer->blobs()[0]->count()), bias(cp.num_output);
+  for (size_t k = 0; k < w.size(); ++k) { const float v = frand(); w[k] = (std::fabs(frand()) < 0.7f) ? 0.f : (v == 0.f ? 0.25f : v); }
+  for (auto &v : bias) v = 0.1f * frand();
+  memcpy(layer->blobs()[0]->mutable_cpu_data(), w.data(), sizeof(float) * w.size());
+  memcpy(layer->blobs()[1]->mutable_cpu_data(), bias.data(), sizeof(float) * bias.size());
+  layer->WeightAlign();
+  int bad = 0;
+  struct Step { int n, h, wd; Caffe::ConvMode mode; const char *what; };
+  const Step steps[] = {{2, 10, 10, Caffe::SCONV_PAR, "as aligned"},      {5, 10, 10, Caffe::SCONV_PAR, "batch grew"},
+                        {3, 14, 9, Caffe::SCONV_PAR, "H x W changed"},    {3, 14, 9, Caffe::LOWERED_GEMM, "-conv_mode 0"},
+                        {3, 14, 9, Caffe::LOWERED_SPARSE, "-conv_mode 1"}, {1, 14, 9, Caffe::SCONV, "-conv_mode 2, batch shrank"}};
+  for (const Step &st : steps) {
+    Caffe::set_conv_mode(st.mode);
+    b0.Reshape(st.n, 8, st.h, st.wd);
+    float *x = b0.mutable_cpu_data();
+    for (int k = 0; k < b0.count(); ++k) x[k] = frand();
+    layer->Forward(bottom, top);
+    std::vector<double> want;
+    naive_conv(b0, cp, w, bias, false, &want, t0.height(), t0.width());
+    const float *got = t0.cpu_data();
+    double maxerr = 0, maxref = 0;
+    for (size_t k = 0; k < want.size(); ++k) {
+      maxerr = std::fmax(maxerr, std::fabs(got[k] - want[k]));
+      maxref = std::fmax(maxref, std::fabs(want[k]));
+    }
+    const double rel = maxerr / std::fmax(1e-6, maxref);
+    const bool ok = rel <= 1e-4 && t0.num() == st.n && t0.height() == st.h && t0.width() == st.wd;
+    printf("%-22s %-28s top %dx%dx%dx%d rel_err=%.2e %s\n", "reshape_after_align", st.what, t0.num(), t0.channels(),
+           t0.height(), t0.width(), rel, ok ? "OK" : "FAIL");
+    bad += ok ? 0 : 1;
+  }
+  Caffe::set_conv_mode(Caffe::SCONV_PAR);
+  return bad;
+}
+
 static ConvolutionParameter P(int m, int k, int pad = 0, int stride = 1, int group = 1, bool bias = true,
                               int dil = 1) {
   ConvolutionParameter cp;
@@ -122,6 +171,8 @@ int main() {
   Caffe::set_conv_mode(Caffe::SCONV);          // -conv_mode 2: same numbers
   bad += run_case<ConvolutionLayer<float> >("res5_branch2b_sconv", 2, 512, 7, 7, P(512, 3, 1, 1, 1, false), 0.9f, false);
   bad += run_case<ConvolutionReLULayer<float> >("conv_relu_k3p1", 2, 16, 13, 13, P(24, 3, 1), 0.8f, true);
+  Caffe::set_conv_mode(Caffe::SCONV_PAR);
+  bad += reshape_case();
   printf(bad ? "shim self-test: %d FAILED\n" : "shim self-test: all OK\n", bad);
   return bad;
 }

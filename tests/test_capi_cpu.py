@@ -66,8 +66,18 @@ def test_plan_lifecycle_and_options_on_host(pkg):
     plan.set_option("conv_mode", pkg.CONV_MODE_SCONV)
     plan.set_option("conv_mode", pkg.CONV_MODE_LOWERED_SPARSE)   # the im2col + csrmm comparator
     plan.set_option("conv_mode", pkg.CONV_MODE_SCONV_PAR)
+    plan.set_option("conv_mode", pkg.CONV_MODE_LOWERED_GEMM)     # -conv_mode 0: dense MFMA kernel
+    plan.set_option("conv_mode", pkg.CONV_MODE_SCONV_PAR)
+    for bad in (-1, 4):
+        with pytest.raises(pkg.EscoinError):
+            plan.set_option("conv_mode", bad)
+    plan.set_option("tiling_batch", 256)
+    plan.set_option("dense_threshold_pct", 30)
+    plan.set_option("dense_gate", 1)
     with pytest.raises(pkg.EscoinError):
-        plan.set_option("conv_mode", 0)              # LOWERED_GEMM is the kernel option KERNEL_DENSE
+        plan.set_option("tiling_batch", -5)
+    with pytest.raises(pkg.EscoinError):
+        plan.set_option("dense_threshold_pct", 101)
     with pytest.raises(pkg.EscoinError):
         plan.set_option("no_such_option", 1)
     with pytest.raises(pkg.EscoinError):

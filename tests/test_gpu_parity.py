@@ -23,8 +23,8 @@ def torch_cuda(pkg):
     return torch
 
 
-def _run(pkg, torch, desc, w, x, bias, kernel):
-    plan = pkg.Plan(desc, kernel=kernel)
+def _run(pkg, torch, desc, w, x, bias, kernel, **options):
+    plan = pkg.Plan(desc, kernel=kernel, **options)
     plan.weight_align(w)
     dev = torch.device("cuda:0")
     top = plan.forward(torch.from_numpy(np.ascontiguousarray(x)).to(dev),
@@ -49,6 +49,11 @@ def test_golden_fixtures(pkg, torch_cuda, path):
         if "generic" in name:
             assert np.array_equal(got, gd.top), "%s: generic kernel must be bit-exact" % gd.name
         assert rel_err(got, gd.top) <= TOL, "%s via %s" % (gd.name, name)
+    # ... and through the tiling (channels per wave, images per tile, blocks) a batch of 256 / 64
+    # gets: the weight stream and tile shapes of the benchmarked configurations
+    for tb in (256, 64):
+        got, name = _run(pkg, torch_cuda, gd.desc(pkg), gd.w, gd.x, gd.bias, pkg.KERNEL_AUTO, tiling_batch=tb)
+        assert rel_err(got, gd.top) <= TOL, "%s via %s, tiling_batch %d" % (gd.name, name, tb)
 
 
 def _config_shapes(synth):
@@ -70,6 +75,99 @@ def test_config_layers_small_batch_vs_oracle(pkg, oracle, synth, torch_cuda):
             if "generic" in name:
                 assert np.array_equal(got, want), s.name
             assert rel_err(got, want) <= TOL, "%s via %s: %g" % (s.name, name, rel_err(got, want))
+
+
+def _config_sets(synth):
+    """BASELINE.json's configurations at their own batch sizes: the tilings bench.py times."""
+    return [("lenet", synth.lenet_conv2(N=64)), ("alexnet", synth.alexnet(N=128)),
+            ("resnet50", synth.resnet50_3x3(N=256)), ("googlenet", synth.googlenet_1x1(N=256))]
+
+
+def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None):
+    """Forward of the WHOLE config batch on device-generated input; images {0, 1 and 3 (inside the
+    first multi-image tile), N/2, N-2, N-1} are checked against the oracle (<= 1e-4)."""
+    dev = torch.device("cuda:0")
+    w, b = synth.pruned_weights(s, seed), synth.bias_vector(s, seed + 1)
+    own = plan is None
+    if own:
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+        plan.weight_align(w)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 2)
+    x = torch.rand((s.N, s.C, s.H, s.W), device=dev, generator=gen) * 2 - 1
+    top = plan.forward(x, torch.from_numpy(b).to(dev) if b is not None else None)
+    torch.cuda.synchronize()
+    imgs = sorted(set(i for i in (images or (0, 1, 3, s.N // 2, s.N - 2, s.N - 1)) if 0 <= i < s.N))
+    idx = torch.tensor(imgs, device=dev)
+    xs, got = x[idx].cpu().numpy(), top[idx].cpu().numpy()
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                    s.dil_h, s.dil_w, s.group)
+    want = oracle.conv_forward(g, xs, w, b, gate=False, threads=4)
+    err = rel_err(got, want)
+    name = plan.kernel_name
+    if own:
+        plan.close()
+    return err, name
+
+
+@pytest.mark.parametrize("which", ["lenet", "alexnet", "resnet50", "googlenet"])
+def test_config_layers_at_config_batch_vs_oracle(pkg, oracle, synth, torch_cuda, which):
+    """Every layer of every BASELINE.json configuration AT ITS CONFIG BATCH (LeNet 64, AlexNet 128,
+    ResNet-50 256, all 39 GoogLeNet 1x1 layers at 256): the tiling the plan picks depends on the
+    batch (channels per wave, images per tile, blocks per pass), so this is the weight stream and
+    the kernel path the headline numbers are measured on."""
+    shapes = dict(_config_sets(synth))[which]
+    for k, s in enumerate(shapes):
+        err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k)
+        assert "tiled" in name, (s.name, name)
+        assert err <= TOL, "%s @N=%d via %s: %g" % (s.name, s.N, name, err)
+
+
+def test_per_group_dense_selection_and_conv_mode_0(pkg, oracle, synth, torch_cuda):
+    """KERNEL_AUTO decides dense (fp32 MFMA) vs sparse per conv group from each group's own density
+    (the reference gates the whole layer on group 0, base_conv_layer.cpp:750-755); conv_mode 0
+    (LOWERED_GEMM, forward_gpu_gemm :713-746) sends every group to the dense kernel; the mode may
+    be flipped on an aligned plan.  Same numbers on every route."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    s = synth.shape("mixed", 5, 24, 13, 13, 36, 3, pad=1, group=3, sparsity=0.9)
+    w = synth.pruned_weights(s, 4)
+    w[12:24] = synth.uniform(9, w[12:24].size).reshape(w[12:24].shape)      # group 1 fully dense
+    b, x = synth.bias_vector(s, 5), synth.activations(s, 6)
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, group=3)
+    want = oracle.conv_forward(g, x, w, b, gate=False)
+    xd, bd = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    plan.weight_align(w)
+    assert "tiled" in plan.kernel_name and "dense_mfma" in plan.kernel_name, plan.kernel_name
+    assert rel_err(plan.forward(xd, bd).cpu().numpy(), want) <= TOL
+    for mode, expect in ((pkg.CONV_MODE_LOWERED_GEMM, "escoin_dense_mfma_kernel"),
+                         (pkg.CONV_MODE_LOWERED_SPARSE, "escoin_csrmm_kernel"),
+                         (pkg.CONV_MODE_SCONV, None), (pkg.CONV_MODE_LOWERED_GEMM, "escoin_dense_mfma_kernel"),
+                         (pkg.CONV_MODE_SCONV_PAR, None)):
+        plan.set_option("conv_mode", mode)
+        if expect:
+            assert plan.kernel_name == expect
+        else:
+            assert "tiled" in plan.kernel_name and "dense_mfma" in plan.kernel_name
+        assert rel_err(plan.forward(xd, bd).cpu().numpy(), want) <= TOL, mode
+    plan.close()
+    # thresholds: 100 = never dense, 0 = any nonzero density is dense; generic kernel in a mixed layer
+    for pct, kernel, has_dense in ((100, pkg.KERNEL_AUTO, False), (0, pkg.KERNEL_AUTO, True)):
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel, dense_threshold_pct=pct)
+        plan.weight_align(w)
+        assert ("dense_mfma" in plan.kernel_name) == has_dense
+        assert (plan.kernel_name == "escoin_dense_mfma_kernel") == has_dense
+        assert rel_err(plan.forward(xd, bd).cpu().numpy(), want) <= TOL
+        plan.close()
+    # a plan aligned in LOWERED_GEMM mode (what `caffe test -conv_mode 0` does) and flipped to SCONV
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s), conv_mode=pkg.CONV_MODE_LOWERED_GEMM)
+    plan.weight_align(w)
+    assert plan.kernel_name == "escoin_dense_mfma_kernel"
+    assert rel_err(plan.forward(xd, bd).cpu().numpy(), want) <= TOL
+    plan.set_option("conv_mode", pkg.CONV_MODE_SCONV_PAR)
+    assert rel_err(plan.forward(xd, bd).cpu().numpy(), want) <= TOL
+    plan.close()
 
 
 def test_sparsity_sweep_60_to_95(pkg, oracle, synth, torch_cuda):
@@ -384,8 +482,13 @@ def test_randomised_tiled_geometries(pkg, oracle, synth, torch_cuda, seed):
             w[:, : (C // group) // 2] = 0.0      # whole input-channel blocks without a nonzero
         g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
         want = oracle.conv_forward(g, x, w, b, gate=False)
-        got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, pkg.KERNEL_AUTO)
-        assert rel_err(got, want) <= TOL, "%s %s via %s: %g" % (s.name, (N, C, H, W, M, K, pad, group, sp), name, rel_err(got, want))
+        # a third of the cases each: the tiling of their own (small) batch, of a batch of 64 and of
+        # a batch of 256 -- the last two give channel groups of 4-24 per wave, several images per
+        # tile and second payload quads, i.e. the streams of the benchmarked configurations
+        tb = (0, 64, 256)[k % 3]
+        got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, pkg.KERNEL_AUTO,
+                         tiling_batch=tb, dense_threshold_pct=100)
+        assert rel_err(got, want) <= TOL, "%s %s tb=%d via %s: %g" % (s.name, (N, C, H, W, M, K, pad, group, sp), tb, name, rel_err(got, want))
         checked += "tiled" in name
     assert checked >= 40      # nearly all of these must have gone down the tiled path
 
