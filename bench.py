@@ -2,19 +2,26 @@
 """bench.py -- conv-layer forward images/s of the direct-sparse-convolution path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload resnet50|alexnet|googlenet|lenet]
+                    [--global-batch B]
 
 A "step" is one pass of the hot path (escoin_forward, the Forward_gpu drop-in) over one batch
 of synthetic input for every conv layer of the workload.  Default workload = BASELINE.json's
 configs[2]: the 16 ResNet-50 3x3 branch2b layers at 90 % weight sparsity, batch 256 per GPU,
 fp32.  For N > 1 the driver launches one process per GPU (torch.distributed.run); the batch
-dimension is sharded (weak scaling: 256 images per GPU), the sparse weights are broadcast
-once from rank 0 over RCCL, and no collective sits in the timed region.
+dimension is sharded, the sparse weights are broadcast once from rank 0 over RCCL, and no
+collective sits in the timed region.  Default = weak scaling (256 images per GPU);
+`--global-batch 2048` = BASELINE.json's configs[3] as strong scaling (2048 / N images per GPU).
+
+After the timed region every rank checks images of every distinct layer shape against the CPU
+oracle (`parity_max_rel_err`, the checker only), and for N > 1 rank 0 recomputes two images of
+every other rank and compares them with that rank's per-image checksums.
 
 Rank 0 prints ONE JSON line on stdout (everything else goes to stderr).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector) = peak FP32 (matrix)
 
 
 def log(*a):
@@ -47,73 +55,455 @@ def workload_layers(synth, name, batch, sparsity):
     raise SystemExit("unknown workload %s" % name)
 
 
+# ---------------------------------------------------------------------------------------------
+# The device side behind a small interface, so that the sharding / broadcast / checking code
+# below is the same code in the 2-rank gloo test (tests/test_bench_gloo.py), where the forward
+# is a stub around the CPU oracle, and on the GPU box.
+# ---------------------------------------------------------------------------------------------
+
+class HipBackend(object):
+    name = "hip"
+    dist_backend = "nccl"
+
+    def __init__(self, pkg, local_rank, kernel):
+        import torch
+        self.torch, self.pkg, self.kernel = torch, pkg, kernel
+        if not torch.cuda.is_available() or pkg.device_count() < 1:
+            raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+
+    def make_plan(self, shape):
+        return self.pkg.Plan(self.pkg.ConvDesc.from_shape(shape), kernel=self.kernel)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+
+def image_seed(shape_index, global_index):
+    """Seed of image `global_index` of the batch of distinct shape `shape_index`: a function of the
+    GLOBAL image index, so results do not depend on how many ranks share the batch."""
+    return 977 * (shape_index + 1) + 7919 * 65536 + global_index * 104729
+
+
+def device_images(be, shape, shape_index, g0, n):
+    """Images [g0, g0 + n) of the global batch, uniform(-1, 1), generated on the device."""
+    torch = be.torch
+    x = torch.empty((n, shape.C, shape.H, shape.W), device=be.device, dtype=torch.float32)
+    gen = torch.Generator(device=be.device)
+    for i in range(n):
+        gen.manual_seed(image_seed(shape_index, g0 + i))
+        x[i] = torch.rand((shape.C, shape.H, shape.W), device=be.device, generator=gen) * 2 - 1
+    return x
+
+
+def layer_weight_seed(lid):
+    return 1000 + 31 * lid
+
+
+def build_layers(be, pkg, synth, shapes, rank, world):
+    """WeightAlign on rank 0, broadcast of the CSR (RCCL on the GPU box), set_csr elsewhere.
+    Returns [(shape, plan, bias, shape_index, layer_id)], seconds spent in the broadcast."""
+    torch = be.torch
+    layers, t_bcast, lid = [], 0.0, 0
+    for si, s in enumerate(shapes):
+        for rep in range(s.count):
+            plan = be.make_plan(s)
+            mg = s.M // s.group
+            if rank == 0:
+                plan.weight_align(synth.pruned_weights(s, layer_weight_seed(lid)))
+            if world > 1:
+                be.synchronize()
+                t0 = time.perf_counter()
+                csr = plan.get_csr() if rank == 0 else None
+                got = pkg.shard.broadcast_csr(csr, s.group, s.group * (mg + 1), synth.nnz_of(s),
+                                              src=0, device=be.device)
+                be.synchronize()
+                t_bcast += time.perf_counter() - t0
+                if rank != 0:
+                    plan.set_csr(*got)
+            bias = synth.bias_vector(s, 2000 + 31 * lid)
+            bias = torch.from_numpy(bias).to(be.device) if bias is not None else None
+            layers.append((s, plan, bias, si, lid))
+            lid += 1
+    return layers, t_bcast
+
+
+def last_layer_of_shape(layers):
+    last = {}
+    for entry in layers:
+        last[entry[3]] = entry
+    return last
+
+
+def parity_check(be, oracle, synth, layers, bottoms, tops, images_per_shape=3):
+    """After the timed region: tops[si] holds the output of the LAST layer of shape si.  Images
+    {0, N/2, N-1} of this rank's shard are recomputed by the CPU oracle from the same inputs and
+    weights (regenerated from their seeds) -- the checker, never the thing measured."""
+    torch = be.torch
+    worst = 0.0
+    for si, (s, plan, bias, _, lid) in sorted(last_layer_of_shape(layers).items()):
+        n = bottoms[si].shape[0]
+        imgs = sorted(set([0, n // 2, n - 1]))[:images_per_shape]
+        idx = torch.tensor(imgs, device=be.device)
+        x = bottoms[si][idx].cpu().numpy()
+        got = tops[si][idx].cpu().numpy()
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                        s.dil_h, s.dil_w, s.group)
+        w = synth.pruned_weights(s, layer_weight_seed(lid))
+        b = synth.bias_vector(s, 2000 + 31 * lid)
+        want = oracle.conv_forward(g, x, w, b, gate=False, threads=min(8, len(imgs)))
+        err = float(np.abs(got.astype(np.float64) - want).max() / max(1e-6, float(np.abs(want).max())))
+        worst = max(worst, err)
+    return worst
+
+
+def cross_rank_check(be, dist, synth, layers, shapes, tops, rank, world, g0_of_rank, n_of_rank):
+    """Per-image checksums of every rank's outputs are gathered; rank 0 recomputes the first and
+    last image of every OTHER rank's shard (same global-index seeds, its own plans) and compares.
+    Returns the worst relative checksum difference (None for world == 1)."""
+    if world == 1:
+        return None
+    torch = be.torch
+    worst = 0.0
+    n_max = max(n_of_rank)
+    for si, (s, plan, bias, _, lid) in sorted(last_layer_of_shape(layers).items()):
+        sums = torch.zeros(n_max, device=be.device, dtype=torch.float64)
+        sums[:tops[si].shape[0]] = tops[si].double().sum(dim=(1, 2, 3))
+        gathered = [torch.zeros_like(sums) for _ in range(world)]
+        dist.all_gather(gathered, sums)
+        if rank != 0:
+            continue
+        for r in range(1, world):
+            if n_of_rank[r] < 1:
+                continue
+            for local in sorted(set([0, n_of_rank[r] - 1])):
+                x = device_images(be, s, si, g0_of_rank[r] + local, 1)
+                y = plan.forward(x, bias)
+                be.synchronize()
+                mine = float(y.double().sum())
+                theirs = float(gathered[r][local])
+                scale = max(1e-6, float(y.double().abs().sum()))
+                worst = max(worst, abs(mine - theirs) / scale)
+    t = torch.tensor([worst], device=be.device, dtype=torch.float64)
+    dist.broadcast(t, src=0)
+    return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------
+
+def host_cpu_info():
+    """Threads this process may use (affinity mask and cgroup quota), physical cores among them,
+    CPU model."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period)))
+    except Exception:
+        pass
+    model, cores = "unknown", set()
+    try:
+        phys = core = proc = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                proc = int(line.split(":")[1])
+            elif line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip():
+                if proc in allowed and phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = proc = None
+    except Exception:
+        pass
+    hw_threads = len(allowed) if quota is None else min(len(allowed), quota)
+    physical = min(hw_threads, len(cores)) if cores else hw_threads
+    return {"hw_threads": hw_threads, "physical_cores": max(1, physical), "model": model,
+            "cgroup_quota": quota}
+
+
+_HOST_INFO = None
+
+
 def cpu_baseline(oracle, synth, shapes, budget_s):
     """Reference CPU sconv path timed on this box's host cores on a bounded sample.
 
-    kind "reference": oracle/_ref = the reference's own kernel (sconv.hpp:594-678) compiled in
-    place, batch loop parallelised over images with OpenMP the way its ICC build does
-    (conv_layer.cpp:41-43); kind "port": the C restatement when _ref is absent."""
-    cores = os.cpu_count() or 1
-    use_ref = oracle.have_ref()
-    per_image_s = 0.0
-    per_image_1t_s = 0.0      # as the reference's g++ build runs it: one thread, serial batch loop
+    kind "reference": oracle/_ref = the reference's own kernels compiled in place.  The layer is
+    aligned ONCE per shape (RefPlan: dense -> CSR outside the timed call, as WeightAlign does) and
+    the whole-batch forward is timed for thread counts {1, physical cores, all hardware threads}
+    (OMP_PROC_BIND=close, OMP_PLACES=cores), OpenMP over the batch the way the reference's ICC
+    build parallelises (conv_layer.cpp:41-43; with batch >= threads / 2 its thread grouping,
+    cpu_info.cpp:483-605, degenerates to exactly that).  `value` = the best thread count with the
+    reference's default loop nest (caffe_cpu_sconv, math_functions.cpp:128-176 -- what `caffe test
+    -conv_mode 2` runs under g++); `best_effort` = the same with the register-blocked kernel
+    sconv_unit_stride (sconv.hpp:57-589, its ICC-only fast path) where the reference's switchboard
+    has an instantiation.  kind "port": the C restatement when oracle/_ref is absent."""
+    info = _HOST_INFO or host_cpu_info()
+    use_ref = oracle.have_ref() and oracle.have_ref_plan()
+    sweep = sorted(set([1, info["physical_cores"], info["hw_threads"]]))
+    share = budget_s / max(1, len(shapes)) / (2 * len(sweep))
+    per_image = {("default", t): 0.0 for t in sweep}
+    per_image.update({("blocked", t): 0.0 for t in sweep})
+    blocked_ok = use_ref
     sample = []
-    share = budget_s / max(1, len(shapes))
     for k, s in enumerate(shapes):
         g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
                         s.dil_h, s.dil_w, s.group)
         w = synth.pruned_weights(s, 1000 + k)
         b = synth.bias_vector(s, 2000 + k)
-        run = (lambda x: oracle.ref_conv_forward(g, x, w, b, threads=cores)) if use_ref else \
-              (lambda x: oracle.conv_forward(g, x, w, b, threads=cores, gate=False))
-        n = cores
-        x = synth.activations(s, 3000 + k, 0, n)
-        run(x)                                        # warm (threads, page faults)
-        t0 = time.perf_counter()
-        run(x)
-        t1 = time.perf_counter() - t0
-        reps = int(max(1, min(64, share / max(t1, 1e-4))))
-        if reps > 1:
-            n = cores * min(reps, 8)
-            x = synth.activations(s, 3000 + k, 0, n)
-            t0 = time.perf_counter()
-            run(x)
-            t1 = time.perf_counter() - t0
-        per_image_s += s.count * t1 / n
-        run1 = (lambda x: oracle.ref_conv_forward(g, x, w, b, threads=1)) if use_ref else \
-               (lambda x: oracle.conv_forward(g, x, w, b, threads=1, gate=False))
-        x1 = synth.activations(s, 3000 + k, 0, 2)
-        run1(x1[:1])
-        t0 = time.perf_counter()
-        run1(x1)
-        per_image_1t_s += s.count * (time.perf_counter() - t0) / 2
-        sample.append("%s:%dimg" % (s.name, n))
-        log("  cpu %-16s %6d img in %.3f s -> %.1f img/s/layer (%d threads)" %
-            (s.name, n, t1, n / t1, cores))
-    return {"value": round(1.0 / per_image_s, 3), "unit": "images/s", "cores": cores,
-            "kind": "reference" if use_ref else "port",
-            "single_thread_value": round(1.0 / per_image_1t_s, 3),
-            "sample": "whole-batch forward of " + ", ".join(sample) +
-                      " per distinct layer shape, OpenMP over images; per-image time summed "
-                      "over all %d layers; single_thread_value = the same on one thread (2 images "
-                      "per shape), the way the reference's g++ build runs its batch loop"
-                      % sum(s.count for s in shapes)}
+        plan = oracle.RefPlan(g, w) if use_ref else None
+        blocked_ok = blocked_ok and plan is not None and plan.has_blocked
+        kinds = ["default"] + (["blocked"] if plan is not None and plan.has_blocked else [])
+        n_max = 0
+        for kind in kinds:
+            for t in sweep:
+                if plan is not None:
+                    run = lambda x, top, t=t, kind=kind: plan.forward(x, b, threads=t, kernel=kind, top=top)
+                else:
+                    run = lambda x, top, t=t: oracle.conv_forward(g, x, w, b, threads=t, gate=False)
+                n = max(t, 2)
+                x = synth.activations(s, 3000 + k, 0, n)
+                top = np.zeros((n, s.M) + synth.out_hw(s), np.float32)
+                run(x, top)                              # warm: threads, page faults
+                t0 = time.perf_counter()
+                run(x, top)
+                t1 = time.perf_counter() - t0
+                reps = int(max(1, min(16, share / max(t1, 1e-4))))
+                if reps > 1:
+                    n = n * reps
+                    x = synth.activations(s, 3000 + k, 0, n)
+                    top = np.zeros((n, s.M) + synth.out_hw(s), np.float32)
+                    run(x, top)
+                    t0 = time.perf_counter()
+                    run(x, top)
+                    t1 = time.perf_counter() - t0
+                per_image[(kind, t)] += s.count * t1 / n
+                n_max = max(n_max, n)
+                log("  cpu %-16s %-8s %4d threads %6d img in %.3f s -> %.1f img/s/layer" %
+                    (s.name, kind, t, n, t1, n / t1))
+        sample.append("%s:<=%dimg" % (s.name, n_max))
+        if plan is not None:
+            plan.close()
+    rate = lambda kind: {t: 1.0 / per_image[(kind, t)] for t in sweep if per_image[(kind, t)] > 0}
+    d = rate("default")
+    best_t = max(d, key=d.get)
+    out = {"value": round(d[best_t], 3), "unit": "images/s", "cores": best_t,
+           "kind": "reference" if use_ref else "port",
+           "cpu_model": info["model"], "physical_cores": info["physical_cores"],
+           "hw_threads": info["hw_threads"],
+           "thread_sweep": {str(t): round(v, 3) for t, v in sorted(d.items())},
+           "single_thread_value": round(d[1], 3),
+           "sample": "whole-batch forward of " + ", ".join(sample) + " per distinct layer shape "
+                     "and thread count, layer aligned once outside the timed call, OpenMP over "
+                     "images; per-image time summed over all %d layers" % sum(s.count for s in shapes)}
+    if blocked_ok:
+        bl = rate("blocked")
+        bt = max(bl, key=bl.get)
+        out["best_effort"] = {"value": round(bl[bt], 3), "unit": "images/s", "cores": bt,
+                              "kernel": "sconv_unit_stride (sconv.hpp:57-589, -DUSE_ICC under g++ -mavx2)",
+                              "thread_sweep": {str(t): round(v, 3) for t, v in sorted(bl.items())}}
+    return out
 
 
-def main():
+def traffic_with_provenance(workload, kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (FETCH_SIZE x 2
+    + WRITE_SIZE, MI355X_MICROARCH.md); collected in a separate rocprofv3 --pmc run
+    (tools/profile.sh), so it comes with the file and the commit that file was last written in."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        value = json.load(open(path)).get(kernel_name)
+    except Exception:
+        return None, None
+    commit = None
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", path],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                timeout=10).stdout.decode().strip() or None
+    except Exception:
+        pass
+    return value, {"file": os.path.relpath(path, ROOT), "commit": commit,
+                   "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE"}
+
+
+def run(args, be, pkg, synth, oracle_loader, dist=None):
+    torch = be.torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    strong = args.global_batch is not None
+    if strong:
+        spans = [pkg.shard.shard_range(args.global_batch, r, world) for r in range(world)]
+        per_rank = [e - b for b, e in spans]
+        g0_of_rank = [b for b, e in spans]
+        batch = per_rank[rank]
+        if min(per_rank) < 1:
+            raise SystemExit("--global-batch %d leaves a rank without images" % args.global_batch)
+        plan_batch = max(per_rank)
+    else:
+        batch = args.batch
+        plan_batch = None
+    shapes, wl_name = workload_layers(synth, args.workload, plan_batch if strong else batch, args.sparsity)
+    per_gpu_batch = batch if strong else shapes[0].N
+    if not strong:
+        per_rank = [per_gpu_batch] * world
+        g0_of_rank = [r * per_gpu_batch for r in range(world)]
+    global_batch = sum(per_rank)
+
+    layers, t_bcast = build_layers(be, pkg, synth, shapes, rank, world)
+
+    # ---- synthetic activations resident in HBM (image k seeded by its GLOBAL index) -----------
+    bottoms, tops = [], []
+    for si, s in enumerate(shapes):
+        bottoms.append(device_images(be, s, si, g0_of_rank[rank], per_gpu_batch))
+        oh, ow = synth.out_hw(s)
+        tops.append(torch.empty((per_gpu_batch, s.M, oh, ow), device=be.device))
+    be.synchronize()
+
+    def step(events=None):
+        # one event between consecutive launches (the end of launch i is the start of launch
+        # i + 1): a launch's duration then includes its dispatch gap, which the step pays for it
+        if events is not None:
+            events[0].record()
+        for li, (s, plan, bias, si, lid) in enumerate(layers):
+            plan.forward(bottoms[si], bias, tops[si])
+            if events is not None:
+                events[li + 1].record()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [[be.event() for _ in range(len(layers) + 1)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    be.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    be.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], device=be.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- self-check of what was just computed (outside the timed region) ----------------------
+    oracle = oracle_loader()
+    parity = parity_check(be, oracle, synth, layers, bottoms, tops)
+    if world > 1:
+        t = torch.tensor([parity], device=be.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parity = float(t.item())
+    cross = cross_rank_check(be, dist, synth, layers, shapes, tops, rank, world, g0_of_rank, per_rank)
+    if rank != 0:
+        return None
+
+    # ---- per-kernel accounting from the events recorded inside the timed region ---------------
+    per_kernel, layer_ms = {}, []
+    for li, (s, plan, bias, si, lid) in enumerate(layers):
+        ms = [ev[k][li].elapsed_time(ev[k][li + 1]) for k in range(args.steps)]
+        m = float(np.mean(ms))
+        layer_ms.append(m)
+        d = per_kernel.setdefault(plan.kernel_name, {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0})
+        d["ms"] += m
+        d["bytes"] += synth.algorithmic_bytes(s, per_gpu_batch)
+        d["flops"] += synth.flops(s, per_gpu_batch)
+        d["launches"] += 1
+    per_layer, seen = [], {}
+    for li, (s, plan, bias, si, lid) in enumerate(layers):
+        seen.setdefault(si, []).append(layer_ms[li])
+    for si, s in enumerate(shapes):
+        m = float(np.mean(seen[si]))
+        name = last_layer_of_shape(layers)[si][1].kernel_name
+        byt, flo = synth.algorithmic_bytes(s, per_gpu_batch), synth.flops(s, per_gpu_batch)
+        t_hbm, t_fma = byt / (HBM_PEAK_GBS * 1e9), flo / (FP32_VECTOR_TFLOPS * 1e12)
+        per_layer.append({"layer": s.name, "count": s.count, "us": round(m * 1e3, 1),
+                          "alg_GBps": round(byt / m / 1e6, 1), "sparse_TFLOPs": round(flo / m / 1e9, 2),
+                          "hbm_frac": round(t_hbm / (m * 1e-3), 4), "fma_frac": round(t_fma / (m * 1e-3), 4),
+                          "binding_frac": round(max(t_hbm, t_fma) / (m * 1e-3), 4)})
+        log("  gpu %-16s %-44s %8.1f us  %7.1f GB/s alg  %6.2f TFLOP/s  binding %.3f  x%d" %
+            (s.name, name, m * 1e3, byt / m / 1e6, flo / m / 1e9, per_layer[-1]["binding_frac"], s.count))
+    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+    traffic, provenance = traffic_with_provenance(args.workload, dom_name)
+    t_bind = sum(max(synth.algorithmic_bytes(s, per_gpu_batch) / (HBM_PEAK_GBS * 1e9),
+                     synth.flops(s, per_gpu_batch) / (FP32_VECTOR_TFLOPS * 1e12)) * s.count for s in shapes)
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_provenance": provenance,
+                "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
+                "launches_per_step": dom["launches"],
+                "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"]),
+                "sparse_tflops": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                # max(bytes / 8 TB/s, flops / 157.3 TF) summed over the step / measured step time:
+                # the fraction of whichever roofline binds each layer (VERDICT r1, item 2)
+                "binding_frac": round(t_bind / (sum(layer_ms) * 1e-3), 4),
+                "per_layer": per_layer}
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = global_batch / (ms_per_step * 1e-3)
+    out = {
+        "metric": "conv-layer fwd images/sec", "value": round(value, 1), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s @%d%% sparsity, batch %d/GPU, fp32" %
+                               (wl_name, round(100 * shapes[0].sparsity), per_gpu_batch),
+                   "global_batch": global_batch, "layers_per_step": len(layers),
+                   "kernel": args.kernel, "parallelism": "batch-sharded x%d" % world,
+                   "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None},
+        "parity_max_rel_err": float("%.3g" % parity),
+        "cross_rank_checksum_rel_diff": None if cross is None else float("%.3g" % cross),
+        "roofline": roofline,
+    }
+    if parity > 1e-4 or (cross is not None and cross > 1e-5):
+        out["parity_failed"] = True
+        log("PARITY FAILURE: parity_max_rel_err=%g cross_rank=%r" % (parity, cross))
+    if world == 1 and not args.no_cpu:
+        log("cpu_baseline (bounded sample, %.0f s budget):" % args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(oracle, synth, shapes, args.cpu_budget)
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="resnet50")
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total images over all GPUs (strong scaling; BASELINE configs[3]: 2048)")
     ap.add_argument("--sparsity", type=float, default=None)
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "tiled"])
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds for the cpu_baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
+
+def main():
+    args = parse_args()
+    # the host's CPU share is read BEFORE any OpenMP runtime exists: with OMP_PROC_BIND set, the
+    # runtime torch loads pins this thread to one core and the affinity mask then reads "2 threads"
+    global _HOST_INFO
+    _HOST_INFO = host_cpu_info()
+    # OpenMP placement for the cpu_baseline leg must be in the environment before libgomp loads
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import torch.distributed as dist
 
     pkg = ge.load_package()
@@ -126,143 +516,14 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`"
                              % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
-    if not torch.cuda.is_available() or pkg.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    kernel = {"auto": pkg.KERNEL_AUTO, "generic": pkg.KERNEL_GENERIC, "tiled": pkg.KERNEL_TILED}[args.kernel]
+    be = HipBackend(pkg, local_rank, kernel)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    shapes, wl_name = workload_layers(synth, args.workload, args.batch, args.sparsity)
-    per_gpu_batch = shapes[0].N
-    kernel = {"auto": pkg.KERNEL_AUTO, "generic": pkg.KERNEL_GENERIC, "tiled": pkg.KERNEL_TILED}[args.kernel]
-
-    # ---- WeightAlign on rank 0, RCCL broadcast of the CSR, set_csr everywhere else ----------
-    layers = []          # (shape, plan, bias, shape_index)
-    t_bcast = 0.0
-    lid = 0
-    for si, s in enumerate(shapes):
-        for rep in range(s.count):
-            plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel)
-            mg = s.M // s.group
-            if rank == 0:
-                plan.weight_align(synth.pruned_weights(s, 1000 + 31 * lid))
-            if world > 1:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                csr = plan.get_csr() if rank == 0 else None
-                got = pkg.shard.broadcast_csr(csr, s.group, s.group * (mg + 1), synth.nnz_of(s),
-                                              src=0, device=dev)
-                torch.cuda.synchronize()
-                t_bcast += time.perf_counter() - t0
-                if rank != 0:
-                    plan.set_csr(*got)
-            bias = synth.bias_vector(s, 2000 + 31 * lid)
-            bias = torch.from_numpy(bias).to(dev) if bias is not None else None
-            layers.append((s, plan, bias, si))
-            lid += 1
-
-    # ---- synthetic activations resident in HBM (image k seeded by its GLOBAL index) -----------
-    gen = torch.Generator(device=dev)
-    bottoms, tops = [], []
-    for si, s in enumerate(shapes):
-        gen.manual_seed(977 * (si + 1) + rank * 7919)
-        bottoms.append(torch.rand((s.N, s.C, s.H, s.W), device=dev, generator=gen) * 2 - 1)
-        oh, ow = synth.out_hw(s)
-        tops.append(torch.empty((s.N, s.M, oh, ow), device=dev))
-    torch.cuda.synchronize()
-
-    def step(events=None):
-        # one HIP event between consecutive launches (the end of launch i is the start of launch
-        # i + 1): half the marker packets of a start/stop pair per launch, and a launch's duration
-        # then includes its dispatch gap, which is what the step pays for it
-        if events is not None:
-            events[0].record()
-        for li, (s, plan, bias, si) in enumerate(layers):
-            plan.forward(bottoms[si], bias, tops[si])
-            if events is not None:
-                events[li + 1].record()
-
-    for _ in range(args.warmup):
-        step()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(layers) + 1)] for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev[k])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    # ---- per-kernel accounting from the HIP events recorded inside the timed region ----------
-    per_kernel = {}
-    layer_ms = []
-    for li, (s, plan, bias, si) in enumerate(layers):
-        ms = [ev[k][li].elapsed_time(ev[k][li + 1]) for k in range(args.steps)]
-        m = float(np.mean(ms))
-        layer_ms.append(m)
-        d = per_kernel.setdefault(plan.kernel_name, {"ms": 0.0, "bytes": 0, "flops": 0, "launches": 0})
-        d["ms"] += m
-        d["bytes"] += synth.algorithmic_bytes(s)
-        d["flops"] += synth.flops(s)
-        d["launches"] += 1
-    seen = set()
-    for li, (s, plan, bias, si) in enumerate(layers):
-        if si in seen:
-            continue
-        seen.add(si)
-        m = layer_ms[li]
-        log("  gpu %-16s %-44s %8.1f us  %7.1f GB/s alg  %6.2f TFLOP/s  x%d" %
-            (s.name, plan.kernel_name, m * 1e3, synth.algorithmic_bytes(s) / m / 1e6,
-             synth.flops(s) / m / 1e9, s.count))
-    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])
-    achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom_name)
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
-                "launches_per_step": dom["launches"],
-                "algorithmic_bytes_per_launch": int(dom["bytes"] / dom["launches"]),
-                "sparse_tflops": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2)}
-
-    ms_per_step = elapsed / args.steps * 1e3
-    value = per_gpu_batch * world / (ms_per_step * 1e-3)
-    out = {
-        "metric": "conv-layer fwd images/sec", "value": round(value, 1), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s @%d%% sparsity, batch %d/GPU, fp32" %
-                               (wl_name, round(100 * shapes[0].sparsity), per_gpu_batch),
-                   "global_batch": per_gpu_batch * world, "layers_per_step": len(layers),
-                   "kernel": args.kernel, "parallelism": "batch-sharded x%d" % world,
-                   "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None},
-        "roofline": roofline,
-    }
-    if world == 1 and not args.no_cpu:
-        oracle = ge.load_oracle()
-        log("cpu_baseline (bounded sample, %.0f s budget):" % args.cpu_budget)
-        out["cpu_baseline"] = cpu_baseline(oracle, synth, shapes, args.cpu_budget)
-    print(json.dumps(out), flush=True)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=be.device)
+    out = run(args, be, pkg, synth, ge.load_oracle, dist if world > 1 else None)
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -366,7 +366,8 @@ int escoin_plan_get_csr(const escoin_plan *p, int *rowptr, int *colidx, float *v
 size_t escoin_plan_workspace_bytes(const escoin_plan *p) { return p ? p->device_bytes : 0; }
 
 const char *escoin_plan_kernel_name(const escoin_plan *p) {
-  if (p && p->aligned && p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && !p->use_dense)
+  if (p && p->aligned && p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE &&
+      p->kernel_choice != ESCOIN_KERNEL_DENSE)
     return lowered_kernel_name();
   return p ? p->kernel_name.c_str() : "";
 }
@@ -379,7 +380,8 @@ int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_de
     return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
   if (n_images == 0) return ESCOIN_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && !p->use_dense)
+  // LOWERED_SPARSE lowers every group, whatever AUTO decided for the direct path
+  if (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && p->kernel_choice != ESCOIN_KERNEL_DENSE)
     return launch_lowered(p, bottom_dev, bias_dev, top_dev, n_images, s);
   if (p->n_dense_groups > 0) {
     const int rc = launch_dense(p, bottom_dev, bias_dev, top_dev, n_images, s);

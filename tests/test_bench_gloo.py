@@ -1,0 +1,164 @@
+"""bench.py's own multi-rank code -- shard spans, CSR broadcast + set_csr, global-index image seeds,
+the max-over-ranks timing, the oracle self-check and the cross-rank checksum check -- driven by two
+gloo ranks on the CPU with the forward stubbed by the oracle (the GPU box runs the same functions
+with the HIP plans and RCCL)."""
+import json
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Event(object):
+    def __init__(self):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return max(1e-6, (other.t - self.t) * 1e3)
+
+
+class _StubPlan(object):
+    """Same surface as caffe_escoin_amd.Plan; arithmetic by the oracle (test stub)."""
+    kernel_name = "oracle_stub"
+
+    def __init__(self, oracle, torch, s):
+        self.o, self.torch, self.s = oracle, torch, s
+        self.w = None
+
+    def weight_align(self, w):
+        self.w = np.ascontiguousarray(w, np.float32)
+
+    def get_csr(self):
+        s = self.s
+        mg, cg = s.M // s.group, s.C // s.group
+        rps, cis, vas, ngs = [], [], [], []
+        for g in range(s.group):
+            rp, ci, va = self.o.dense2csr(self.w[g * mg:(g + 1) * mg].reshape(mg, cg * s.KH * s.KW))
+            rps.append(rp); cis.append(ci); vas.append(va); ngs.append(len(ci))
+        return np.concatenate(rps), np.concatenate(cis), np.concatenate(vas), np.array(ngs, np.int32)
+
+    def set_csr(self, rp, ci, va, ng):
+        s = self.s
+        mg, cg = s.M // s.group, s.C // s.group
+        w = np.zeros((s.M, cg * s.KH * s.KW), np.float32)
+        off = 0
+        for g in range(s.group):
+            r = rp[g * (mg + 1):(g + 1) * (mg + 1)]
+            for m in range(mg):
+                w[g * mg + m, ci[off + r[m]:off + r[m + 1]]] = va[off + r[m]:off + r[m + 1]]
+            off += int(ng[g])
+        self.w = w.reshape(s.M, cg, s.KH, s.KW)
+
+    def forward(self, x, bias=None, top=None):
+        s = self.s
+        g = self.o.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                        s.dil_h, s.dil_w, s.group)
+        y = self.o.conv_forward(g, x.numpy(), self.w, None if bias is None else bias.numpy(), gate=False)
+        y = self.torch.from_numpy(y)
+        if top is not None:
+            top.copy_(y)
+            return top
+        return y
+
+
+class _StubBackend(object):
+    name = "stub"
+    dist_backend = "gloo"
+
+    def __init__(self, oracle):
+        import torch
+        self.torch, self.oracle = torch, oracle
+        self.device = torch.device("cpu")
+
+    def make_plan(self, shape):
+        return _StubPlan(self.oracle, self.torch, shape)
+
+    def synchronize(self):
+        pass
+
+    def event(self):
+        return _Event()
+
+
+def _worker(rank, world, port, out_dir, argv):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import bench
+    pkg = ge.load_package()
+    oracle = ge.load_oracle()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    out = bench.run(bench.parse_args(argv), _StubBackend(oracle), pkg, pkg.synth, ge.load_oracle, dist)
+    assert (out is None) == (rank != 0)
+    if out is not None:
+        with open(os.path.join(out_dir, "out.json"), "w") as f:
+            json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, argv):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), argv), nprocs=2, join=True)
+    return json.load(open(os.path.join(str(tmp_path), "out.json")))
+
+
+def test_bench_weak_scaling_two_ranks(tmp_path):
+    out = _run(tmp_path, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "lenet",
+                          "--batch", "3", "--no-cpu"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 6 and out["config"]["weight_broadcast_ms"] is not None
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert out["parity_max_rel_err"] <= 1e-4                  # every rank's shard vs the oracle
+    assert out["cross_rank_checksum_rel_diff"] <= 1e-5        # rank 1's images recomputed on rank 0
+    assert "parity_failed" not in out
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "binding_frac"}
+
+
+def test_bench_strong_scaling_uneven_shards(tmp_path):
+    """--global-batch 5 over 2 ranks: 3 + 2 images; value counts all 5."""
+    out = _run(tmp_path, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "alexnet",
+                          "--global-batch", "5", "--no-cpu"])
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 5
+    assert abs(out["value"] - 5 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
+    assert out["parity_max_rel_err"] <= 1e-4 and out["cross_rank_checksum_rel_diff"] <= 1e-5
+    assert out["config"]["layers_per_step"] == 4
+
+
+def test_image_seeds_depend_on_the_global_index_only():
+    sys.path.insert(0, ROOT)
+    import torch
+    import __graft_entry__ as ge
+    import bench
+    pkg = ge.load_package()
+    be = _StubBackend(None)
+    s = pkg.synth.lenet_conv2(N=8)[0]
+    whole = bench.device_images(be, s, 0, 0, 8)
+    parts = torch.cat([bench.device_images(be, s, 0, 0, 3), bench.device_images(be, s, 0, 3, 5)])
+    assert torch.equal(whole, parts)
+    assert not torch.equal(whole[0], whole[1])
+    assert not torch.equal(whole, bench.device_images(be, s, 1, 0, 8))
+
+
+def test_host_cpu_info_respects_affinity():
+    sys.path.insert(0, ROOT)
+    import bench
+    info = bench.host_cpu_info()
+    assert 1 <= info["physical_cores"] <= info["hw_threads"] <= len(os.sched_getaffinity(0))
+    assert isinstance(info["model"], str)

@@ -1,0 +1,80 @@
+"""SURVEY 8 f2 / f3 on the GPU: the `caffe test` look-alike (tools/caffe_test.py) and the
+.caffemodel / persisted-CSR hand-off feeding the HIP path (reference: tools/caffe.cpp:270-370,
+Net::CopyTrainedLayersFrom -> WeightAlign, net.cpp:785-822)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "caffe_test.py")
+
+
+def _tool(*argv):
+    out = subprocess.run([sys.executable, TOOL] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text
+    return text
+
+
+def test_caffe_test_export_then_weights_from_file(tmp_path):
+    """--export writes the pruned AlexNet as a .caffemodel; a second run takes every layer's
+    weights and biases from that file (CopyTrainedLayersFrom), WeightAligns them and checks each
+    layer against the oracle."""
+    path = str(tmp_path / "alexnet_pruned.caffemodel")
+    assert "4 convolution layers" in _tool("--model", "alexnet", "--export", path)
+    assert os.path.getsize(path) > 1 << 20
+    text = _tool("--model", "alexnet", "--weights", path, "--check", "--batch", "6", "--iterations", "1")
+    assert "weights of 4 / 4 layers taken from the file" in text
+    assert "oracle check: worst relative error" in text and "[cxh] Total CONV time" in text
+
+
+def test_caffe_test_every_conv_mode(tmp_path):
+    for mode in ("0", "1", "2", "3"):
+        text = _tool("--model", "lenet", "--conv_mode", mode, "--check", "--batch", "5", "--iterations", "1")
+        assert "oracle check: worst relative error" in text, mode
+
+
+def test_caffe_test_resnet50_chain_with_dense_1x1():
+    """All 53 convolutions of ResNet-50's bottleneck blocks chained (dense 1x1 on the MFMA kernel
+    around the sparse 3x3), every layer checked against the oracle, per-type buckets printed."""
+    text = _tool("--model", "resnet50_chain", "--batch", "4", "--iterations", "1", "--check")
+    assert "over 52 conv layers" in text or "over 53 conv layers" in text, text
+    assert "sparse 3x3" in text and "dense 1x1" in text and "conv / total" in text
+    assert "dense_mfma" in text and "tiled" in text
+
+
+def test_persisted_csr_feeds_the_hip_path(tmp_path, pkg, oracle, synth):
+    """save_aligned -> load_aligned -> escoin_plan_set_csr -> forward: a layer restored from the
+    persisted CSR (no dense blob, no dense -> CSR) computes what the oracle computes."""
+    import torch
+    from caffe_escoin_amd import caffemodel as cm
+    dev = torch.device("cuda:0")
+    shapes = [synth.alexnet(N=3)[0], synth.resnet50_3x3(N=3)[2], synth.googlenet_1x1(N=3)[4]]
+    entries, inputs = {}, {}
+    for k, s in enumerate(shapes):
+        w, b = synth.pruned_weights(s, 40 + k), synth.bias_vector(s, 50 + k)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+        plan.weight_align(w)
+        entries[s.name] = (pkg.ConvDesc.from_shape(s), plan.get_csr())
+        inputs[s.name] = (s, w, b)
+        plan.close()
+    path = str(tmp_path / "aligned.npz")
+    cm.save_aligned(path, entries)
+    for name, (fields, csr) in cm.load_aligned(path).items():
+        s, w, b = inputs[name]
+        plan = pkg.Plan(pkg.ConvDesc(*fields))
+        plan.set_csr(*csr)
+        x = synth.activations(s, 60)
+        got = plan.forward(torch.from_numpy(x).to(dev),
+                           torch.from_numpy(b).to(dev) if b is not None else None).cpu().numpy()
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                        s.dil_h, s.dil_w, s.group)
+        assert rel_err(got, oracle.conv_forward(g, x, w, b, gate=False)) <= 1e-4, name
+        plan.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""`caffe test -conv_mode {1,2,3}` for the sparse convolution layers only.
+"""`caffe test -conv_mode {0,1,2,3}` for the convolution layers.
 
 The reference's `caffe test` (tools/caffe.cpp:262-362) loads a model + a pruned .caffemodel,
 runs `-iterations` forward passes and prints "[cxh] Total CONV time" per pass
@@ -9,8 +9,16 @@ that for the layers on the SCONV path: every sparse conv layer of the named mode
 convolution time from HIP events.  Non-convolution layers are out of scope.
 
     python tools/caffe_test.py --model resnet50 --iterations 5
+    python tools/caffe_test.py --model resnet50_chain --iterations 5      # + the dense 1x1 convs
     python tools/caffe_test.py --model alexnet --export /tmp/alexnet_pruned.caffemodel
     python tools/caffe_test.py --model alexnet --weights /tmp/alexnet_pruned.caffemodel --check
+
+--model resnet50_chain runs ResNet-50's 16 bottleneck blocks as a chain: the dense 1x1 convolutions
+(branch2a / branch2c / branch1; `EscConvolution` in the reference's prototxt, here the fp32 MFMA
+kernel) around the sparse 3x3 ones, activations flowing from block to block, with the per-type time
+buckets of Net::GetConvTime / GetOtherTime / GetTotalTime (net.cpp:516-565) printed the way
+tools/caffe.cpp:338-343 does.  BatchNorm / Scale / ReLU / Eltwise are not part of the hot path: a
+torch stand-in keeps the activations in range and is timed in the "other" bucket.
 
 --weights takes the pruned weights (and biases) from a .caffemodel by layer name instead of the
 synthetic generator; --export writes the synthetic pruned model in that format, so the same
@@ -44,13 +52,141 @@ def model_layers(synth, model, batch, sparsity):
     return out
 
 
+# ResNet-50 bottleneck stages after conv1 + pool1 (models/resnet/test_sconv.prototxt):
+# (channels of the 3x3, output channels, blocks, stride of the first block)
+_RESNET50_STAGES = [(64, 256, 3, 1), (128, 512, 4, 2), (256, 1024, 6, 2), (512, 2048, 3, 2)]
+
+
+def resnet50_chain(synth, batch, sparsity):
+    """[(name, kind, shape, relu, role)]: role in {"2a", "2b", "2c", "1"}; kind "sparse" for the
+    pruned 3x3 (branch2b), "dense" for the 1x1 ones (sparsity 0)."""
+    out = []
+    cin, hw = 64, 56
+    for si, (mid, cout, blocks, stride) in enumerate(_RESNET50_STAGES):
+        for b in range(blocks):
+            st = stride if b == 0 else 1
+            tag = "res%d%s" % (si + 2, "abcdef"[b])
+            ohw = hw // st
+            if b == 0:
+                out.append((tag + "_branch1", "dense",
+                            synth.shape(tag + "_branch1", batch, cin, hw, hw, cout, 1, stride=st, bias=False, sparsity=0.0),
+                            False, "1"))
+            out.append((tag + "_branch2a", "dense",
+                        synth.shape(tag + "_branch2a", batch, cin, hw, hw, mid, 1, stride=st, bias=False, sparsity=0.0),
+                        True, "2a"))
+            out.append((tag + "_branch2b", "sparse",
+                        synth.shape(tag + "_branch2b", batch, mid, ohw, ohw, mid, 3, pad=1, bias=False, sparsity=sparsity),
+                        True, "2b"))
+            out.append((tag + "_branch2c", "dense",
+                        synth.shape(tag + "_branch2c", batch, mid, ohw, ohw, cout, 1, bias=False, sparsity=0.0),
+                        False, "2c"))
+            cin, hw = cout, ohw
+    return out
+
+
+def run_chain(args, pkg, synth):
+    import torch
+    if not torch.cuda.is_available() or pkg.device_count() < 1:
+        raise SystemExit("caffe_test.py needs a HIP device: the product path has no CPU fallback")
+    dev = torch.device("cuda", 0)
+    batch = args.batch or 256
+    chain = resnet50_chain(synth, batch, 0.9 if args.sparsity is None else args.sparsity)
+    print("[cxh] GPU device name: %s" % torch.cuda.get_device_name(0))
+    plans, weights = [], []
+    t0 = time.perf_counter()
+    for i, (name, kind, s, relu, role) in enumerate(chain):
+        w = synth.pruned_weights(s, 1000 + 31 * i)
+        # keep the activations O(1) through 16 blocks: He-style scale for the surviving weights
+        w = (w * np.float32(np.sqrt(6.0 / max(1.0, (1.0 - s.sparsity) * w[0].size)))).astype(np.float32)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), conv_mode=args.conv_mode)
+        if args.dense_gate:
+            plan.set_option("dense_gate", 1)
+        plan.weight_align(w)
+        plans.append(plan)
+        weights.append(w)
+    torch.cuda.synchronize()
+    print("[cxh] WeightAlign of %d layers: %.1f ms" % (len(chain), 1e3 * (time.perf_counter() - t0)))
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    x0 = torch.rand((batch, 64, 56, 56), device=dev, generator=g) * 2 - 1
+    oracle = ge.load_oracle() if args.check else None
+    worst = 0.0
+
+    def conv(i, x, bucket):
+        nonlocal worst
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        y = plans[i].forward(x)
+        b.record()
+        bucket.append((chain[i][1], a, b))
+        if oracle is not None:
+            s = chain[i][2]
+            geom = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                               s.dil_h, s.dil_w, s.group)
+            want = oracle.conv_forward(geom, x[:1].cpu().numpy(), weights[i], None, relu=chain[i][3], gate=False)
+            got = y[:1].cpu().numpy()
+            err = float(np.abs(got.astype(np.float64) - want).max() / max(1e-6, np.abs(want).max()))
+            if err > 1e-4:
+                raise SystemExit("%s: relative error %.3g vs the oracle" % (chain[i][0], err))
+            worst = max(worst, err)
+        return y
+
+    def other(fn, bucket):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        y = fn()
+        b.record()
+        bucket.append(("other", a, b))
+        return y
+
+    print("Running for %d iterations." % args.iterations)
+    sums = {"sparse": 0.0, "dense": 0.0, "other": 0.0}
+    for it in range(args.iterations + 1):          # iteration 0 is an untimed warm-up
+        bucket = []
+        x = x0
+        i = 0
+        while i < len(chain):
+            shortcut = x
+            if chain[i][4] == "1":
+                shortcut = conv(i, x, bucket)
+                i += 1
+            y = conv(i, x, bucket)        # branch2a (+ReLU)
+            y = conv(i + 1, y, bucket)    # branch2b (+ReLU): the sparse 3x3
+            y = conv(i + 2, y, bucket)    # branch2c
+            # Eltwise + ReLU (+ a BatchNorm-like rescale): not the hot path, torch stand-in
+            x = other(lambda: torch.relu_(y.add_(shortcut)).mul_(0.7071), bucket)
+            i += 3
+        torch.cuda.synchronize()
+        if oracle is not None and it == 0:
+            print("[cxh] oracle check: worst relative error %.3g over %d conv layers (image 0)" % (worst, len(chain)))
+            oracle = None
+        if it == 0:
+            continue
+        t = {"sparse": 0.0, "dense": 0.0, "other": 0.0}
+        for kind, a, b in bucket:
+            t[kind] += a.elapsed_time(b)
+        for k in t:
+            sums[k] += t[k]
+        print("[cxh] Total CONV time: %.2f ms" % (t["sparse"] + t["dense"]))
+        print("[cxh] Total forwarding time: %.2f ms" % sum(t.values()))
+    n = max(1, args.iterations)
+    conv_t = (sums["sparse"] + sums["dense"]) / n
+    print("[cxh] Average over %d iterations (batch %d): CONV %.3f ms (sparse 3x3 %.3f ms in 16 layers, "
+          "dense 1x1 %.3f ms in %d layers), other %.3f ms, total %.3f ms; conv / total = %.1f %%" %
+          (n, batch, conv_t, sums["sparse"] / n, sums["dense"] / n, len(chain) - 16, sums["other"] / n,
+           (conv_t + sums["other"] / n), 100.0 * conv_t / max(1e-9, conv_t + sums["other"] / n)))
+    print("kernels: sparse -> %s, dense -> %s" % (plans[2].kernel_name, plans[0].kernel_name))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--weights", default=None, help=".caffemodel with pruned weights (by layer name)")
     ap.add_argument("--export", default=None, help="write the synthetic pruned model here and exit")
-    ap.add_argument("--conv_mode", type=int, default=3, choices=[1, 2, 3],
-                    help="1 = LOWERED_SPARSE comparator (im2col + csrmm), 2/3 = direct sparse convolution")
+    ap.add_argument("--conv_mode", type=int, default=3, choices=[0, 1, 2, 3],
+                    help="0 = LOWERED_GEMM (dense MFMA kernel), 1 = LOWERED_SPARSE comparator "
+                         "(im2col + csrmm), 2/3 = direct sparse convolution")
     ap.add_argument("--iterations", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--sparsity", type=float, default=None)
@@ -62,6 +198,8 @@ def main():
     pkg = ge.load_package()
     from caffe_escoin_amd import caffemodel as cm
     synth = pkg.synth
+    if args.model == "resnet50_chain":
+        return run_chain(args, pkg, synth)
     layers = model_layers(synth, args.model, args.batch, args.sparsity)
 
     weights = {}
