@@ -67,6 +67,8 @@ static void free_device(escoin_plan *p) {
   p->col_bytes = 0;
   if (p->d_dense_w) (void)hipFree(p->d_dense_w);
   p->d_dense_w = nullptr;
+  if (p->d_ktab) (void)hipFree(p->d_ktab);
+  p->d_ktab = nullptr;
   p->d_rowptr = p->d_taps = nullptr;
   p->d_vals = nullptr;
   p->d_stream = nullptr;
@@ -147,16 +149,19 @@ static int upload(escoin_plan *p, hipStream_t stream) {
   if (p->use_dense) p->dense_mask = ~0ull;
   p->sparse_mask = p->n_dense_groups == 0 ? ~0ull : ~p->dense_mask & (G >= 64 ? ~0ull : ((1ull << G) - 1));
   if (p->n_dense_groups > 0) {
-    std::vector<float> dw((size_t)g.d.M * g.kdim, 0.f);
+    const size_t lda = (size_t)dense_lda(g.kdim);
+    std::vector<float> dw(((size_t)g.d.M + dense_spare_rows()) * lda, 0.f);
     for (int grp = 0; grp < G; ++grp)
       for (int m = 0; m < g.Mg; ++m)
         for (int j = p->rowptr[grp][m]; j < p->rowptr[grp][m + 1]; ++j)
-          dw[((size_t)grp * g.Mg + m) * g.kdim + p->colidx[grp][j]] = p->values[grp][j];
+          dw[((size_t)grp * g.Mg + m) * lda + p->colidx[grp][j]] = p->values[grp][j];
     ESCOIN_HIP_TRY(hipMalloc(&p->d_dense_w, sizeof(float) * dw.size()));
     p->device_bytes += sizeof(float) * dw.size();
     ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_dense_w, dw.data(), sizeof(float) * dw.size(),
                                   hipMemcpyHostToDevice, stream));
     ESCOIN_HIP_TRY(hipStreamSynchronize(stream));
+    const int rc = dense_build_ktab(p, stream);
+    if (rc != ESCOIN_OK) return rc;
   }
   if (p->use_dense) {
     p->kernel_name = dense_kernel_name();

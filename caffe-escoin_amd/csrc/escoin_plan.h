@@ -86,7 +86,8 @@ struct escoin_plan {
   // dense fallback (fp32 MFMA implicit GEMM), chosen per conv group: bit g of dense_mask = group g
   // goes to the MFMA kernel, bit g of sparse_mask = to the sparse kernels (layers with more than 64
   // groups take one decision for all of them: both masks are then all-ones / zero)
-  float *d_dense_w = nullptr;     // [M][Cg*KH*KW]
+  float *d_dense_w = nullptr;     // [M + dense_spare_rows()][dense_lda(Cg*KH*KW)], zero padded
+  int *d_ktab = nullptr;          // im2col decode per k: {image offset, dy | dx << 16} (dense_mfma.hip)
   bool use_dense = false;         // every group dense
   unsigned long long dense_mask = 0, sparse_mask = ~0ull;
   int n_dense_groups = 0, n_sparse_groups = 0;
@@ -125,6 +126,9 @@ const char *lowered_kernel_name();
 int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, float *top,
                  int n_images, hipStream_t stream);
 const char *dense_kernel_name();
+int dense_build_ktab(escoin_plan *p, hipStream_t stream);
+int dense_lda(int K);          // floats per row of d_dense_w (K rounded up to whole k-steps)
+int dense_spare_rows();       // zero rows after row M - 1
 
 // Index of the k-th set bit of `mask` (k < popcount): blockIdx -> conv group when only some groups
 // of a layer run in a launch.  Wave-uniform scalar code on the device.

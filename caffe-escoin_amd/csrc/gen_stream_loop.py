@@ -52,6 +52,7 @@ SGPR_LAST = 45
 MAX_SLOTS2 = 6
 ABL = set()                  # timing-only ablations (see main())
 PRIO_HI = 1                  # priority of a wave's even groups (odd groups run at 0)
+HOIST = True                 # extract a group's meta / indices ahead of its first FMAs
 
 
 def bfe(dst, src, off, width):
@@ -118,24 +119,50 @@ def body2(L, n, p, band):
         A("s_waitcnt lgkmcnt(%d)" % (2 if n > 3 else 1))
     else:
         A("s_waitcnt lgkmcnt(%d)" % (4 if n > 3 else 3))   # X(k), P0(k) landed
-    A("s_set_gpr_idx_idx s%d" % META_P[1 - p])
-    pk4v(L, 0, p)
-    A("v_readfirstlane_b32 s%d, v%d" % (meta, P0[p]))
-    A("s_lshr_b32 s%d, s%d, 21" % (HDR2, meta))          # row offset / 32 of group k+2
-    for r in range(1, n):
-        t = IXT[r % 2]
-        if r == 3:
-            A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))   # the second quad (older than the prefetches) landed
-            A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
-            A("s_set_gpr_idx_idx s%d" % META2)           # record 3: bits 0..7 of meta2 as they are
-        else:
-            src, sh = (meta, 7 * r) if r < 3 else (META2, 7 * (r - 3))
-            if sh == 14 and r < 3:
-                A(bfe(t, src, 14, 7))                      # bit 21 above it belongs to the row offset
+    if HOIST:
+        # meta of THIS group and the accumulator indices of its records 1, 2 are extracted before
+        # record 0's FMAs: the VALU -> SGPR -> SALU -> M0 chain then runs under those 4 packed FMAs
+        # instead of between record 0 and record 1
+        A("v_readfirstlane_b32 s%d, v%d" % (meta, P0[p]))
+        A("s_lshr_b32 s%d, s%d, 21" % (HDR2, meta))          # row offset / 32 of group k+2
+        for r in range(1, min(n, 3)):
+            t = IXT[r % 2]
+            if r == 2:
+                A(bfe(t, meta, 14, 7))
             else:
-                A("s_lshr_b32 s%d, s%d, %d" % (t, src, sh))
-            A("s_set_gpr_idx_idx s%d" % t)
-        pk4v(L, r, p)
+                A("s_lshr_b32 s%d, s%d, %d" % (t, meta, 7 * r))
+        A("s_set_gpr_idx_idx s%d" % META_P[1 - p])
+        pk4v(L, 0, p)
+        for r in range(1, n):
+            t = IXT[r % 2]
+            if r == 3:
+                A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))
+                A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
+                for r2 in range(4, n):
+                    A("s_lshr_b32 s%d, s%d, %d" % (IXT[r2 % 2], META2, 7 * (r2 - 3)))
+                A("s_set_gpr_idx_idx s%d" % META2)
+            else:
+                A("s_set_gpr_idx_idx s%d" % t)
+            pk4v(L, r, p)
+    else:
+        A("s_set_gpr_idx_idx s%d" % META_P[1 - p])
+        pk4v(L, 0, p)
+        A("v_readfirstlane_b32 s%d, v%d" % (meta, P0[p]))
+        A("s_lshr_b32 s%d, s%d, 21" % (HDR2, meta))          # row offset / 32 of group k+2
+        for r in range(1, n):
+            t = IXT[r % 2]
+            if r == 3:
+                A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))   # the second quad (older than the prefetches) landed
+                A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
+                A("s_set_gpr_idx_idx s%d" % META2)           # record 3: bits 0..7 of meta2 as they are
+            else:
+                src, sh = (meta, 7 * r) if r < 3 else (META2, 7 * (r - 3))
+                if sh == 14 and r < 3:
+                    A(bfe(t, src, 14, 7))                      # bit 21 above it belongs to the row offset
+                else:
+                    A("s_lshr_b32 s%d, s%d, %d" % (t, src, sh))
+                A("s_set_gpr_idx_idx s%d" % t)
+            pk4v(L, r, p)
     # s_add_u32 x, x, -1: SCC = carry = (x was not 0) = another group follows in this bucket
     A("s_add_u32 s%d, s%d, -1" % (CNT, CNT))
     if p == 0:
@@ -204,8 +231,9 @@ def main():
     import os
     if os.environ.get("ESC_GEN_NOPRIO"):
         ABL.add("noprio")
-    global PRIO_HI
+    global PRIO_HI, HOIST
     PRIO_HI = int(os.environ.get("ESC_GEN_PRIO_HI", PRIO_HI))
+    HOIST = os.environ.get("ESC_GEN_HOIST", "1") != "0"
     out = sys.stdout
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))

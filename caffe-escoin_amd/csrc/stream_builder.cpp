@@ -213,7 +213,7 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
         for (int r = 0; r < rows_per_blk; ++r) {
           const std::vector<Rec> &rr = rows[r];
           const int icl = r / g.KH, kr = r % g.KH;
-          const uint32_t off = (uint32_t)(((size_t)icl * t.plane_ch_floats + (size_t)kr * t.RS) * 4);
+          const uint32_t off = (uint32_t)(((size_t)icl * t.plane_ch_floats + (size_t)kr * t.nseg * t.RS) * 4);
           for (size_t b = 0; b < rr.size(); b += kMaxSlots) {
             Group gr;
             gr.lds_off = off;

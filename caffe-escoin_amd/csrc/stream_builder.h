@@ -4,7 +4,11 @@
 // The tiled kernel (sconv_tiled.hip) computes, per workgroup, an output block of
 //   (oc_waves * G output channels) x (pix_waves * 2 * 64 output "quads" of 4 adjacent pixels)
 // Input planes are staged in LDS per block of `icb` input channels in a zero-padded layout:
-//   lds[ic_local][segment][plane_row][RS floats]     RS = 4*S4 >= W, columns >= W are zero
+//   lds[ic_local][plane_row][segment][RS floats]     RS = 4*S4 >= W, columns >= W are zero
+// (segments -- the whole images of a tile -- are interleaved row by row, and a workgroup's lanes
+// are numbered (row, segment, quad): the 64 quads a wave reads for one input row are then 1 KiB of
+// consecutive LDS whatever the image size, so the reads are bank-conflict free and tile B is
+// always tile A + 1 KiB.)
 // A lane owns TWO quads (tile A and tile B: the same lane position in two consecutive
 // 64-quad slabs of the workgroup's flattened (segment,row) space).  For every
 // (ic_local, kernel row kr) -- an "input row" -- the wave reads its two aligned quads ONCE and

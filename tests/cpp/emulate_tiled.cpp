@@ -100,7 +100,7 @@ static int run(const Case &cs) {
                 const int yin = y0 + pr - g.pad_h;
                 if (yin < 0 || yin >= t.H) continue;
                 for (int xx = 0; xx < t.W; ++xx)
-                  lds[(size_t)icl * t.plane_ch_floats + (size_t)seg * t.plane_seg_floats + pr * t.RS + xx] =
+                  lds[(size_t)icl * t.plane_ch_floats + ((size_t)pr * t.nseg + seg) * t.RS + xx] =
                       x[(((size_t)n * g.C + cg * g.Cg + ic) * t.H + yin) * t.W + xx];
               }
             }
@@ -136,9 +136,8 @@ static int run(const Case &cs) {
                   for (int lane = 0; lane < 64; ++lane)
                     for (int tl = 0; tl < 2; ++tl) {
                       const int fr = (pw * 2 + tl) * t.rows_per_slab + lane / t.S4;
-                      const int seg = fr / t.tr, yl = fr % t.tr, j = lane % t.S4;
-                      size_t base = ((size_t)seg * t.plane_rows + yl) * t.RS + 4 * j;
-                      if (seg >= t.nseg) base = 0;
+                      const int j = lane % t.S4;
+                      const size_t base = (size_t)fr * t.RS + 4 * j;   // lanes = (row, segment, quad)
                       const size_t a = base + row_off / 4;
                       float *A = &acc[((size_t)wave * 64 + lane) * kAccAll + tl * kAccRegsPerTile];
                       for (int s = 0; s < n; ++s) {
@@ -175,8 +174,8 @@ static int run(const Case &cs) {
             for (int tl = 0; tl < 2; ++tl)
               for (int lane = 0; lane < 64; ++lane) {
                 const int fr = (pw * 2 + tl) * t.rows_per_slab + lane / t.S4;
-                const int seg = fr / t.tr, yl = fr % t.tr, j = lane % t.S4;
-                if (seg >= t.nseg) continue;
+                const int yl = fr / t.nseg, seg = fr % t.nseg, j = lane % t.S4;
+                if (yl >= t.tr) continue;
                 int n, y;
                 if (t.band_mode) { n = tile / t.bands; y = (tile % t.bands) * t.tr + yl; }
                 else { n = tile * t.nseg + seg; y = yl; }

@@ -29,6 +29,7 @@ def time_plan(torch, plan, x, bias, top, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--dense-only", action="store_true", help="only time the dense MFMA kernel")
     args = ap.parse_args()
     import torch
     pkg = ge.load_package()
@@ -53,6 +54,11 @@ def main():
         td = time_plan(torch, pd, x, bias, top)
         pd.close()
         dense_flops = 2.0 * s.N * oh * ow * s.M * (s.C // s.group) * s.KH * s.KW
+        if args.dense_only:
+            print("%-28s %4d@%dx%d -> %4d %dx%d  dense %8.1f us  %6.1f TFLOP/s" %
+                  (s.name, s.C, s.H, s.W, s.M, s.KH, s.KW, td, dense_flops / td / 1e6))
+            sys.stdout.flush()
+            continue
         row, cross = [], None
         for sp in sparsities:
             ss = s._replace(sparsity=sp)

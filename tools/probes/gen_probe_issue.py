@@ -163,6 +163,36 @@ for n in (2, 3, 4):
 VARIANTS.append(("abody_n2_sdwa", 16, "same, n=2, address add as SDWA (no idx0)", (lambda: a_body(2, True))))
 
 
+def idx_body(kind, per):
+    """16 pk_fma, the accumulator index (M0) changed every `per` of them: what one index switch
+    costs.  kind: "set" = s_set_gpr_idx_idx, "mov" = s_mov_b32 m0, "movnop" = s_mov_b32 m0 + s_nop 0,
+    "shift" = s_lshr_b32 m0 (shift and set in one SALU instruction), "none" = no switch."""
+    L = []
+    pks = pkrun(16)
+    for i, pkl in enumerate(pks):
+        if i % per == 0 and kind != "none":
+            sreg = 45 + (i // per) % 4          # s45..s48 hold 0xC000 | {0, 4, 8, 12}
+            if kind == "set":
+                L.append("s_set_gpr_idx_idx s%d" % sreg)
+            elif kind == "mov":
+                L.append("s_mov_b32 m0, s%d" % sreg)
+            elif kind == "movnop":
+                L.append("s_mov_b32 m0, s%d" % sreg)
+                L.append("s_nop 0")
+            elif kind == "shift":
+                L.append("s_lshr_b32 m0, s49, %d" % (16 * ((i // per) % 2)))   # s49 = 0xC004C000
+        L.append(pkl)
+    return L
+
+
+for kind in ("none", "set", "mov", "movnop", "shift"):
+    for per in (2, 4, 8):
+        if kind == "none" and per != 4:
+            continue
+        VARIANTS.append(("idx_%s_%d" % (kind, per), 16, "16 pk_fma, M0 switched every %d by %s" % (per, kind),
+                         (lambda kind=kind, per=per: idx_body(kind, per))))
+
+
 def kernel(name, lines, unroll):
     body = "\n".join('      "%s\\n"' % ln for ln in lines * unroll)
     return """
@@ -190,7 +220,7 @@ HEADER = r"""// GENERATED by gen_probe_issue.py -- hardware probe, not product c
 #include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
-#define CLOB "memory", "scc", "m0", "s40", "s41", "s42", "s43", "s44", \
+#define CLOB "memory", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", \
   "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49", \
   "v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67", \
   "v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85", \
@@ -205,6 +235,7 @@ HEADER = r"""// GENERATED by gen_probe_issue.py -- hardware probe, not product c
   "v_mov_b32 v52, 0xC000\n v_mov_b32 v53, 0.5\n v_mov_b32 v54, 0xC000\n v_mov_b32 v55, 0.5\n" \
   "v_mov_b32 v56, 0xC000\n v_mov_b32 v57, 0.5\n v_mov_b32 v58, 0xC000\n v_mov_b32 v59, 0.5\n" \
   "s_mov_b32 s40, 0\n s_mov_b32 s41, 0\n s_mov_b32 s42, 0\n s_mov_b32 s43, 0\n s_mov_b32 s44, 0xC000\n" \
+  "s_mov_b32 s45, 0xC000\n s_mov_b32 s46, 0xC004\n s_mov_b32 s47, 0xC008\n s_mov_b32 s48, 0xC00C\n s_mov_b32 s49, 0xC004C000\n" \
   "s_set_gpr_idx_on s44, gpr_idx(SRC2,DST)\n" :: "v"(l16) : CLOB)
 #define SINK(out) do { float r0; asm volatile("s_set_gpr_idx_off\n v_add_f32 %0, v80, v82" : "=v"(r0) :: "v80", "v82"); \
   if (r0 == 12345.678f) out[threadIdx.x] = r0; } while (0)
@@ -234,6 +265,11 @@ __global__ void __attribute__((amdgpu_num_vgpr(32))) k_sem(float *out, int nops)
       ".long 0x7EF80546\n"
       "v_pk_fma_f32 v[80:81], v[70:71], v[40:41], v[80:81] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
       "2:\n"
+      // plain SALU write of M0 (index 2), consumed by the very next VALU instruction: v82/v83 += (3, 6)
+      "s_mov_b32 s45, 0xC002\n s_mov_b32 m0, s45\n"
+      "v_pk_fma_f32 v[80:81], v[70:71], v[40:41], v[80:81] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
+      "s_mov_b32 s45, 0xC006C000\n s_lshr_b32 m0, s45, 16\n"
+      "v_pk_fma_f32 v[80:81], v[70:71], v[40:41], v[80:81] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n"
       // SDWA add while idx = 4 (variant 0) .. then idx 2 via v72: does the dst move?
       ".long 0x7EF80548\n s_nop 4\n"
       "v_add_u32_sdwa v33, s42, v32 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
@@ -275,7 +311,7 @@ int main(int argc, char **argv) {
     float h[10]; CK(hipMemcpy(h, dout, sizeof(h), hipMemcpyDeviceToHost));
     printf("sem (%s): acc v80..87 =", nops ? "no nop after v_readfirstlane m0" : "s_nop 4 after v_readfirstlane m0");
     for (int i = 0; i < 8; ++i) printf(" %g", h[i]);
-    printf("   [expect v84=3 v85=6]   sdwa add: v33=%g v35=%g [v33=107: SDWA ignores indexing]\n", h[8], h[9]);
+    printf("   [v_readfirstlane->m0: expect v84=3 v85=6; s_mov m0: v82=3 v83=6; s_lshr m0: v86=3 v87=6]   sdwa add: v33=%g v35=%g [v33=107: SDWA ignores indexing]\n", h[8], h[9]);
   }
   const int iters = 4000;
 """
@@ -299,6 +335,7 @@ def main():
     out.write(r"""
   printf("%-16s %6s %10s %10s %12s  %s\n", "variant", "w/SIMD", "TFLOP/s", "ns/iter", "cyc/iter@2.4", "what");
   for (const Var &v : vars) {
+    if (argc > 1 && !strstr(v.name, argv[1])) continue;
     for (int w : {1, 2, 4}) {
       const double ms = time_kernel(v.fn, w, iters, dout);
       const double n_it = (double)iters * v.unroll;
