@@ -7,22 +7,28 @@
 //     C[Mg x P] = A[Mg x K] * B[K x P],   K = Cg*KH*KW,  P = N*OH*OW,
 // A = the dense weights, B = the im2col view gathered on the fly (any stride / pad / dilation).
 //
-// Workgroup = 4 waves on a BM x 128 tile (BM = 128: waves 2 x 2, 64 x 64 each; BM = 64 for layers
-// with <= 64 output channels per group: waves 1 x 4, 64 x 32 each), two workgroups per CU.  A
-// wave's tile is 2 x {2,1} blocks of v_mfma_f32_32x32x2_f32 (exact fp32 products and sums).
-// k-steps of 32, double buffered through LDS: the global loads of step s + 1 fly under the 64 (32)
-// MFMAs of step s, one barrier per step.
-//   A tile  [m][32 k], 16-byte chunks XOR-swizzled by (m >> 1) & 7: a lane's four consecutive k of
-//           one row come out as ONE conflict-free ds_read_b128.  The MFMA's two k-slots (lane
-//           halves) take k0 + 4h + t, t = 0..3: the sum over k is just taken in another order.
-//   B tile  [32 k][128 p + 4]: the staging writes are 16-byte (pointwise layers) or 4-byte
-//           (gathered) and conflict-free, the fragment reads ds_read_b32.
-//   im2col  the decode k -> (ic, kr, kc) is a per-layer table built at WeightAlign (ktab: element
-//           offset inside the image and the (dy, dx) used for the border test), read with scalar
-//           loads -- k is wave-uniform --, instead of two integer divisions per gathered element.
+// Persistent workgroups (two per CU, 4 waves each) walk the (pixel tile, channel tile) pairs; a
+// BM x 128 output tile (BM = 128: waves 2 x 2, 64 x 64 each; BM = 64 for layers with <= 64 output
+// channels per group: waves 1 x 4, 64 x 32 each) is 2 x {2,1} blocks of v_mfma_f32_32x32x2_f32
+// per wave (exact fp32 products and sums).  The loop runs over k-steps of 32 ACROSS tiles: while
+// step s is multiplied, the operands of step s + 1 -- the next tile's first step included -- are
+// copied global -> LDS by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write), one
+// barrier per step.
+//   A tile  [m][32 k], 16-byte chunks XOR-swizzled by (m >> 1) & 7 (a DMA lane simply fetches the
+//           chunk that belongs in its slot): a lane's four consecutive k of one row come out as
+//           ONE conflict-free ds_read_b128.  The MFMA's two k-slots (lane halves) take
+//           k0 + 4h + t, t = 0..3: the sum over k is just taken in another order.
+//   B tile  [32 k][128 p].  Pointwise layers (1x1, stride 1, no padding, H*W % 4 == 0): the column
+//           matrix IS the bottom blob, 16 bytes per DMA lane.  Otherwise 4 bytes per lane, gathered:
+//           the decode k -> (ic, kr, kc) is a per-layer table built at WeightAlign (element offset
+//           inside the image, (dy, dx) for the border test) read with scalar loads -- k is
+//           wave-uniform; a tap outside the image gets an out-of-range offset and the buffer
+//           descriptor's range check delivers the zero of the padding.
 // Bias and ReLU are fused in the epilogue.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "escoin_plan.h"
@@ -30,8 +36,9 @@
 namespace escoin {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4d __attribute__((ext_vector_type(4)));
 
-constexpr int kBN = 128, kBK = 32, kBPad = 4;
+constexpr int kBN = 128, kBK = 32;
 
 struct DenseArgs {
   const float *__restrict__ in;
@@ -42,11 +49,38 @@ struct DenseArgs {
   int n_images, C, H, W, M, OH, OW;
   int pad_h, pad_w, stride_h, stride_w;
   int Cg, Mg, K, lda, P, relu;
-  int vec_b;                       // pointwise layer whose pixels can be staged 16 bytes at a time
-  unsigned long long group_mask;   // conv groups this launch covers (all ones: every group)
+  int n_ptiles, n_mtiles, n_groups;        // tiles: pixel x channel x conv group (of this launch)
+  unsigned in_bytes, w_bytes;              // buffer descriptor ranges
+  unsigned long long group_mask;           // conv groups this launch covers (all ones: every group)
 };
 
 __device__ __forceinline__ int a_swizzle(int row, int chunk) { return row * kBK + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+// One LDS-DMA instruction: 64 lanes x 16 (4) bytes from buffer offsets voff + soff (range-checked
+// against the descriptor: out-of-range lanes deliver zeros) to LDS bytes [lds_addr, + 1024 (256)).
+// Inline asm: the compiler must not see these as pending LDS writes (it would drain the queue with
+// s_waitcnt vmcnt(0) in front of the next ds_read); the kernel waits for them itself.
+__device__ __forceinline__ void dma16(u32x4d rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // (wave-uniform by construction)
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_mov_b32 m0, %0\n s_nop 0\n buffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void dma4(u32x4d rsrc, unsigned lds_addr, unsigned voff) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %0\n s_nop 0\n buffer_load_dword %1, %2, 0 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
+__device__ __forceinline__ u32x4d make_rsrc(const void *p, unsigned bytes) {
+  const unsigned long long q = reinterpret_cast<unsigned long long>(p);
+  u32x4d r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)q);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32) & 0xFFFFu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
 
 template <int WROWS, bool POINTWISE4>
 __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) {
@@ -54,169 +88,181 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
   constexpr int WCOLS = 4 / WROWS;           // waves along the pixel axis
   constexpr int WN = kBN / WCOLS;            // columns per wave: 64 or 32
   constexpr int NB = WN / 32;                // 32-column MFMA blocks per wave
-  constexpr int A_CHUNKS = BM * (kBK / 4) / 256;   // 16-byte chunks of A staged per thread: 4 or 2
-  __shared__ __attribute__((aligned(16))) float sA[2][BM * kBK];
-  __shared__ __attribute__((aligned(16))) float sB[2][kBK][kBN + kBPad];
+  constexpr int A_DMA = BM / 8 / 4;          // 1 KiB A pieces per wave and k-step: 4 or 2
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  __shared__ __attribute__((aligned(1024))) float sA[2][BM * kBK];
+  __shared__ __attribute__((aligned(1024))) float sB[2][kBK * kBN];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WCOLS, wn = wave % WCOLS;
-  const int cg = a.group_mask == ~0ull ? (int)blockIdx.z : nth_set_bit(a.group_mask, blockIdx.z);
-  const int m0 = blockIdx.y * BM;                   // first output channel (group-local)
-  const int p0 = blockIdx.x * kBN;                  // first flattened output pixel
+  const int li = lane & 31, lh = lane >> 5;
   const int ohw = a.OH * a.OW;
   const int hw = a.H * a.W;
+  const int nk = (a.K + kBK - 1) / kBK;
+  const long n_tiles = (long)a.n_ptiles * a.n_mtiles * a.n_groups;
+  const u32x4d rA = make_rsrc(a.w, a.w_bytes), rB = make_rsrc(a.in, a.in_bytes);
+  const unsigned ldsA = (unsigned)(size_t)(&sA[0][0]), ldsB = (unsigned)(size_t)(&sB[0][0]);
 
-  // ---- A staging: chunk c = tid + 256 q -> row c / 8, 16-byte chunk c % 8 of the k-step.  The
-  // weight matrix is stored zero-padded to whole k-steps and with 128 spare rows, so every load is
-  // an unconditional 16-byte load (rows past Mg bring in another group's weights: those
-  // accumulator rows are never stored). ----
-  const float *wbase = a.w + (size_t)(cg * a.Mg + m0) * a.lda;
+  // ---- A pieces of this wave: piece i = wave + 4 q covers rows 8 i .. 8 i + 7, lane l -> row
+  // 8 i + l / 8, LDS slot l % 8, which holds chunk (l % 8) ^ ((row >> 1) & 7): the same for every q
+  const unsigned voffA = (unsigned)(((lane >> 3) * a.lda + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) << 2)) * 4);
 
-  // ---- B staging ----
-  //  pointwise, 16 bytes: thread -> pixels 4 (tid % 32) .. + 3, k = tid / 32 + 8 q, q < 4
-  //  gathered,   4 bytes: thread -> pixel tid % 128,          k = 16 (tid / 128) + q, q < 16
-  const int bp = POINTWISE4 ? (tid & 31) * 4 : (tid & 127);
-  const int bk = POINTWISE4 ? (tid >> 5) : 16 * (wave >> 1);   // (gathered: wave-uniform)
-  // Columns past P (the last tile) are clamped to the last pixel: they are computed and never
-  // stored, so that every staging load below is unconditional (a conditional load makes the
-  // compiler wait for it at the join, in front of the MFMAs it is supposed to fly under).
-  const int p = min(p0 + bp, a.P - (POINTWISE4 ? 4 : 1));
-  const int n = p / ohw;
-  const int rem = p - n * ohw;
-  int ih0 = 0, iw0 = 0;
-  if (!POINTWISE4) {
-    const int oh = rem / a.OW, ow = rem - oh * a.OW;
-    ih0 = oh * a.stride_h - a.pad_h;
-    iw0 = ow * a.stride_w - a.pad_w;
-  }
-  // pointwise: the pixel's address in channel 0 of its group; gathered: the image's first element
-  // of that channel (the window's offset is added per tap, 0 for a tap outside the image)
-  const float *img = a.in + ((size_t)n * a.C + (size_t)cg * a.Cg) * hw + (POINTWISE4 ? rem : 0);
-  const int win = ih0 * a.W + iw0;
+  auto tile_coords = [&](long tile, int &cg, int &m0, int &p0) {
+    const int mt = (int)(tile % a.n_mtiles);
+    const long r = tile / a.n_mtiles;
+    const int pt = (int)(r % a.n_ptiles);
+    const int gsel = (int)(r / a.n_ptiles);
+    cg = a.group_mask == ~0ull ? gsel : nth_set_bit(a.group_mask, gsel);
+    m0 = mt * BM;
+    p0 = pt * kBN;
+  };
 
-  f32x16 acc[2][NB];
+  // ---- B addressing of the tile being FETCHED (recomputed when the fetch moves to a new tile) ----
+  //  pointwise: lane -> pixels p0 + 4 (l % 32) .. + 3 of row pair (l / 32)
+  //  gathered:  lane -> pixel p0 + 64 half + l, half = 0, 1
+  unsigned fb_pix[2] = {0u, 0u};     // byte offset of the lane's pixel (window origin) in the blob
+  int fb_ih0[2] = {0, 0}, fb_iw0[2] = {0, 0};
+  int f_cg = 0, f_m0 = 0, f_p0 = 0;
+  auto fetch_setup = [&](long tile) {
+    tile_coords(tile, f_cg, f_m0, f_p0);
+    if (POINTWISE4) {
+      const int p = min(f_p0 + 4 * (lane & 31), a.P - 4);
+      const int n = p / ohw, rem = p - n * ohw;
+      fb_pix[0] = (unsigned)((((size_t)n * a.C + (size_t)f_cg * a.Cg + (lane >> 5)) * hw + rem) * 4);
+    } else {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int half = 0; half < 2; ++half) {
+        const int p = min(f_p0 + 64 * half + lane, a.P - 1);
+        const int n = p / ohw, rem = p - n * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        fb_ih0[half] = oh * a.stride_h - a.pad_h;
+        fb_iw0[half] = ow * a.stride_w - a.pad_w;
+        fb_pix[half] = (unsigned)((((long)n * a.C + (long)f_cg * a.Cg) * hw + (long)fb_ih0[half] * a.W + fb_iw0[half]) * 4);
+      }
+    }
+  };
+  auto fetch = [&](int kstep, int buf) {
+    const int k0 = kstep * kBK;
+    // A: rows f_m0 + 8 i .., columns k0 .. k0 + 31 of the padded matrix
+    const unsigned sa = (unsigned)((((size_t)f_cg * a.Mg + f_m0) * a.lda + k0) * 4);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = f32x16{0};
-
-  float4 av[A_CHUNKS];
-  float4 bv4[POINTWISE4 ? 4 : 1];
-  float bv[POINTWISE4 ? 1 : 16];
-  unsigned bmask = 0u;
-  auto gather = [&](int k0) {
-#pragma unroll
-    for (int q = 0; q < A_CHUNKS; ++q) {
-      const int c = tid + 256 * q;
-      av[q] = *reinterpret_cast<const float4 *>(wbase + (size_t)(c >> 3) * a.lda + k0 + ((c & 7) << 2));
+    for (int q = 0; q < A_DMA; ++q) {
+      const int i = wave + 4 * q;
+      dma16(rA, ldsA + (unsigned)(buf * BM * kBK * 4 + i * 1024), voffA, sa + (unsigned)(i * 8 * a.lda * 4));
     }
     if (POINTWISE4) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        // k past K (last k-step): any valid address will do, A holds zeros there
-        const int k = min(k0 + bk + 8 * q, a.K - 1);
-        bv4[q] = *reinterpret_cast<const float4 *>(img + (size_t)k * hw);
+        const int i = wave + 4 * q;          // rows k0 + 2 i, k0 + 2 i + 1
+        dma16(rB, ldsB + (unsigned)(buf * kBK * kBN * 4 + i * 1024), fb_pix[0], (unsigned)((size_t)(k0 + 2 * i) * hw * 4));
       }
     } else {
-      // the 16 taps of this wave's half of the k-step: 128 contiguous bytes at a wave-uniform
-      // address -> two s_load_dwordx16, issued once, ahead of the 16 gathers
-      const int4 *tp = reinterpret_cast<const int4 *>(a.ktab + k0 + bk);
-      int4 tt[8];
+      // this wave's 8 rows of the k-step: their taps are 64 contiguous bytes at a wave-uniform address
+      const int4 *tp = reinterpret_cast<const int4 *>(a.ktab + k0 + 8 * wave);
+      int4 tt[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) tt[q] = tp[q];
-      bmask = 0u;
+      for (int q = 0; q < 4; ++q) tt[q] = tp[q];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int toff = (q & 1) ? tt[q >> 1].z : tt[q >> 1].x;
-        const int tdyx = (q & 1) ? tt[q >> 1].w : tt[q >> 1].y;
-        const int ih = ih0 + (tdyx & 0xFFFF), iw = iw0 + (tdyx >> 16);
-        const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        bv[q] = img[ok ? win + toff : 0];      // unconditional load; zeroed when staged
-        bmask |= ok ? (1u << q) : 0u;
-      }
-    }
-  };
-  auto stage = [&](int buf) {
+      for (int kk = 0; kk < 8; ++kk) {
+        const int toff = (kk & 1) ? tt[kk >> 1].z : tt[kk >> 1].x;
+        const int tdyx = (kk & 1) ? tt[kk >> 1].w : tt[kk >> 1].y;
 #pragma unroll
-    for (int q = 0; q < A_CHUNKS; ++q) {
-      const int c = tid + 256 * q;
-      *reinterpret_cast<float4 *>(&sA[buf][a_swizzle(c >> 3, c & 7)]) = av[q];
-    }
-    if (POINTWISE4) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&sB[buf][bk + 8 * q][bp]) = bv4[q];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) sB[buf][bk + q][bp] = ((bmask >> q) & 1u) ? bv[q] : 0.f;
-    }
-  };
-
-  gather(0);
-  stage(0);
-  __syncthreads();
-  int buf = 0;
-  const int li = lane & 31, lh = lane >> 5;
-  for (int k0 = 0; k0 < a.K; k0 += kBK, buf ^= 1) {
-    const bool more = k0 + kBK < a.K;
-    if (more) gather(k0 + kBK);                     // flies under the MFMAs below
-    // fragments of k-group kg + 1 are read while the MFMAs of k-group kg run
-    // lane (i, h): A rows wm * 64 + {0, 32} + i, k = 8 kg + 4 h + t; B columns wn * WN + 32 j + i
-    const int ra = wm * 64 + li;
-    float4 fa[2][2];
-    float fb[2][4][NB];
-    auto read_frags = [&](int kg, int s) {
-      fa[s][0] = *reinterpret_cast<const float4 *>(&sA[buf][a_swizzle(ra, 2 * kg + lh)]);
-      fa[s][1] = *reinterpret_cast<const float4 *>(&sA[buf][a_swizzle(ra + 32, 2 * kg + lh)]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) fb[s][t][j] = sB[buf][8 * kg + 4 * lh + t][wn * WN + 32 * j + li];
-    };
-    read_frags(0, 0);
-#pragma unroll
-    for (int kg = 0; kg < kBK / 8; ++kg) {
-      const int s = kg & 1;
-      if (kg + 1 < kBK / 8) read_frags(kg + 1, s ^ 1);
-      // keep the order: next group's LDS reads first, then this group's MFMAs (left alone, the
-      // scheduler sinks each read to just above its use and every 4 MFMAs wait for LDS)
-      __builtin_amdgcn_sched_barrier(0);
-      const float a0[4] = {fa[s][0].x, fa[s][0].y, fa[s][0].z, fa[s][0].w};
-      const float a1[4] = {fa[s][1].x, fa[s][1].y, fa[s][1].z, fa[s][1].w};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], fb[s][t][j], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], fb[s][t][j], acc[1][j], 0, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+          const int ih = fb_ih0[half] + (tdyx & 0xFFFF), iw = fb_iw0[half] + (tdyx >> 16);
+          const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+          dma4(rB, ldsB + (unsigned)(buf * kBK * kBN * 4 + (8 * wave + kk) * 512 + half * 256),
+               ok ? fb_pix[half] + (unsigned)(toff * 4) : kOOB);
         }
       }
     }
-    if (more) stage(buf ^ 1);                       // the other buffer: last read one step ago
-    __syncthreads();
-  }
+  };
 
-  // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+  f32x16 acc[2][NB];
+  long tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  fetch_setup(tile);
+  fetch(0, 0);
+  long f_tile = tile;     // tile of the step being fetched next
+  int f_k = 1;            // ... and its k-step
+  if (f_k == nk) { f_k = 0; f_tile += gridDim.x; if (f_tile < n_tiles) fetch_setup(f_tile); }
+  int buf = 0;
+  for (; tile < n_tiles; tile += gridDim.x) {
+    int cg, m0, p0;
+    tile_coords(tile, cg, m0, p0);
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int pj = p0 + wn * WN + 32 * j + li;
-    if (pj >= a.P) continue;
-    const int nn = pj / ohw;
-    const int rr = pj - nn * ohw;
-    float *obase = a.out + ((size_t)nn * a.M + (size_t)cg * a.Mg) * ohw + rr;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int j = 0; j < NB; ++j) acc[i][j] = f32x16{0};
+    for (int ks = 0; ks < nk; ++ks, buf ^= 1) {
+      // this wave's pieces of the step have landed (and the stores of the last epilogue are out) ...
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // ... everyone's have, and everyone is done with the other buffer
+      if (f_tile < n_tiles) {
+        fetch(f_k, buf ^ 1);
+        if (++f_k == nk) {
+          f_k = 0;
+          f_tile += gridDim.x;
+          if (f_tile < n_tiles) fetch_setup(f_tile);
+        }
+      }
+      // fragments of k-group kg + 1 are read while the MFMAs of k-group kg run
+      // lane (i, h): A rows wm * 64 + {0, 32} + i, k = 8 kg + 4 h + t; B columns wn * WN + 32 j + i
+      const int ra = wm * 64 + li;
+      float4 fa[2][2];
+      float fb[2][4][NB];
+      auto read_frags = [&](int kg, int s) {
+        fa[s][0] = *reinterpret_cast<const float4 *>(&sA[buf][a_swizzle(ra, 2 * kg + lh)]);
+        fa[s][1] = *reinterpret_cast<const float4 *>(&sA[buf][a_swizzle(ra + 32, 2 * kg + lh)]);
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wm * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (m >= a.Mg) continue;
-        float v = acc[i][j][reg];
-        if (a.bias) v += a.bias[cg * a.Mg + m];
-        if (a.relu) v = fmaxf(v, 0.f);
-        obase[(size_t)m * ohw] = v;
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) fb[s][t][j] = sB[buf][(8 * kg + 4 * lh + t) * kBN + wn * WN + 32 * j + li];
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int kg = 0; kg < kBK / 8; ++kg) {
+        const int s = kg & 1;
+        if (kg + 1 < kBK / 8) read_frags(kg + 1, s ^ 1);
+        // keep the order: next group's LDS reads first, then this group's MFMAs (left alone, the
+        // scheduler sinks each read to just above its use and every 4 MFMAs wait for LDS)
+        __builtin_amdgcn_sched_barrier(0);
+        const float a0[4] = {fa[s][0].x, fa[s][0].y, fa[s][0].z, fa[s][0].w};
+        const float a1[4] = {fa[s][1].x, fa[s][1].y, fa[s][1].z, fa[s][1].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], fb[s][t][j], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], fb[s][t][j], acc[1][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int pj = p0 + wn * WN + 32 * j + li;
+      if (pj >= a.P) continue;
+      const int nn = pj / ohw;
+      const int rr = pj - nn * ohw;
+      float *obase = a.out + ((size_t)nn * a.M + (size_t)cg * a.Mg) * ohw + rr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = m0 + wm * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+          if (m >= a.Mg) continue;
+          float v = acc[i][j][reg];
+          if (a.bias) v += a.bias[cg * a.Mg + m];
+          if (a.relu) v = fmaxf(v, 0.f);
+          obase[(size_t)m * ohw] = v;
+        }
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 const char *dense_kernel_name() { return "escoin_dense_mfma_kernel"; }
@@ -224,6 +270,19 @@ const char *dense_kernel_name() { return "escoin_dense_mfma_kernel"; }
 // Layout of the dense weight matrix on the device: rows of dense_lda(K) floats (whole k-steps,
 // zero padded), kDenseSpareRows zero rows after the last one.
 int dense_lda(int K) { return (K + kBK - 1) / kBK * kBK; }
+
+static int dense_device_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    hipDeviceProp_t prop;
+    c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
 int dense_spare_rows() { return 128; }
 
 // The im2col decode of every k (one table per layer, built in WeightAlign): element offset of tap
@@ -268,21 +327,32 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   if (g.d.dil_h * (g.d.KH - 1) > 0x7FFE || g.d.dil_w * (g.d.KW - 1) > 0x7FFE)
     return fail(ESCOIN_EINVAL, "dense kernel: dilated kernel extent does not fit 15 bits");
   a.P = (int)P;
+  // the operands are addressed through buffer descriptors with 32-bit byte offsets
+  const size_t in_bytes = (size_t)n_images * g.d.C * g.d.H * g.d.W * 4;
+  const size_t w_bytes = ((size_t)g.d.M + dense_spare_rows()) * a.lda * 4;
+  if (in_bytes >= 0xFFFFFFF0ull || w_bytes >= 0xFFFFFFF0ull)
+    return fail(ESCOIN_EINVAL, "dense kernel: bottom blob or weight matrix exceeds the 4 GiB descriptor range");
+  a.in_bytes = (unsigned)in_bytes;
+  a.w_bytes = (unsigned)w_bytes;
   // pointwise (is_1x1_, base_conv_layer.cpp:374-379) with whole quads of pixels per image: the
   // column matrix IS the bottom blob and is staged 16 bytes at a time
   const bool pointwise = g.d.KH == 1 && g.d.KW == 1 && g.d.stride_h == 1 && g.d.stride_w == 1 &&
                          g.d.pad_h == 0 && g.d.pad_w == 0;
-  a.vec_b = pointwise && (g.d.H * g.d.W) % 4 == 0 && (reinterpret_cast<uintptr_t>(bottom) & 15) == 0;
+  const bool vec_b = pointwise && (g.d.H * g.d.W) % 4 == 0 && (reinterpret_cast<uintptr_t>(bottom) & 15) == 0 && P >= 4;
   a.group_mask = p->use_dense ? ~0ull : p->dense_mask;
   const int bm = g.Mg <= 64 ? 64 : 128;
-  dim3 grid((unsigned)((P + kBN - 1) / kBN), (unsigned)((g.Mg + bm - 1) / bm),
-            (unsigned)(p->use_dense ? g.d.group : p->n_dense_groups));
-  if (grid.y > 65535u || grid.z > 65535u) return fail(ESCOIN_EINVAL, "dense kernel: grid too large");
+  a.n_ptiles = (int)((P + kBN - 1) / kBN);
+  a.n_mtiles = (g.Mg + bm - 1) / bm;
+  a.n_groups = p->use_dense ? g.d.group : p->n_dense_groups;
+  const long tiles = (long)a.n_ptiles * a.n_mtiles * a.n_groups;
+  // persistent: two 4-wave workgroups per CU walk the tiles
+  const long slots = 2l * dense_device_cus();
+  dim3 grid((unsigned)std::min<long>(tiles, slots), 1, 1);
   if (bm == 64) {
-    if (a.vec_b) hipLaunchKernelGGL((escoin_dense_mfma_kernel<1, true>), grid, dim3(256), 0, stream, a);
+    if (vec_b) hipLaunchKernelGGL((escoin_dense_mfma_kernel<1, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((escoin_dense_mfma_kernel<1, false>), grid, dim3(256), 0, stream, a);
   } else {
-    if (a.vec_b) hipLaunchKernelGGL((escoin_dense_mfma_kernel<2, true>), grid, dim3(256), 0, stream, a);
+    if (vec_b) hipLaunchKernelGGL((escoin_dense_mfma_kernel<2, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((escoin_dense_mfma_kernel<2, false>), grid, dim3(256), 0, stream, a);
   }
   ESCOIN_HIP_TRY(hipGetLastError());

@@ -22,7 +22,7 @@ int fail(int code, const std::string &msg) {
 
 // Density above which KERNEL_AUTO sends a conv group to the dense fp32-MFMA kernel: the measured
 // crossover between the tiled sparse kernel and the dense kernel (profiles/r02_crossover.md).
-constexpr int kDefaultDenseThresholdPct = 60;
+constexpr int kDefaultDenseThresholdPct = 50;
 
 static int out_dim(int in, int k, int pad, int stride, int dil) {
   // conv_layer.cpp:16-19
