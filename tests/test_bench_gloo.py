@@ -136,7 +136,7 @@ def test_bench_strong_scaling_uneven_shards(tmp_path):
     out = _run(tmp_path, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "alexnet",
                           "--global-batch", "5", "--no-cpu"])
     assert out["scaling"] == "strong" and out["config"]["global_batch"] == 5
-    assert abs(out["value"] - 5 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
+    assert abs(out["value"] - 5 / (out["ms_per_step"] * 1e-3)) <= 0.06 + 1e-3 * out["value"]   # (value is rounded to 0.1)
     assert out["parity_max_rel_err"] <= 1e-4 and out["cross_rank_checksum_rel_diff"] <= 1e-5
     assert out["config"]["layers_per_step"] == 4
 
