@@ -326,10 +326,14 @@ def traffic_with_provenance(workload, kernel_name):
     if not os.path.exists(path):
         return None, None
     try:
-        value = json.load(open(path)).get(kernel_name)
+        blob = json.load(open(path))
+        value = blob.get(kernel_name)
     except Exception:
         return None, None
-    commit = None
+    commit = blob.get("_commit")
+    if commit:      # written by tools/save_profile.py next to the numbers
+        return value, {"file": os.path.relpath(path, ROOT), "commit": commit, "saved": blob.get("_saved"),
+                       "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE"}
     try:
         commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", path],
                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,

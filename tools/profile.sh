@@ -7,7 +7,7 @@ TAG=${1:-r01}
 WL=${2:-resnet50}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof_${TAG}_${WL}
+OUT=${PROF_OUT:-gpurun_out}/prof_${TAG}_${WL}
 rm -rf $OUT; mkdir -p $OUT
 ARGS="bench.py --workload $WL --steps 5 --warmup 2 --no-cpu"
 # the kernel-stats pass runs bench.py with its default step counts (the command the driver times)
@@ -15,4 +15,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 be
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > /dev/null 2> $OUT/pmc_write.log
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > /dev/null 2> $OUT/pmc_sq.log
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > /dev/null 2> $OUT/pmc_sq2.log
+echo done > $OUT/done.txt
 find $OUT -name "*.csv" | head -20

@@ -40,7 +40,7 @@ def main():
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                             r["Percentage"], r["MinNs"], r["MaxNs"]])
     out = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         for fn in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
             for r in csv.DictReader(open(fn)):
                 k = short(r["Kernel_Name"])
@@ -65,6 +65,14 @@ def main():
             traffic["_fetch_kib_per_launch"] = cs["FETCH_SIZE"]["per_launch"]
             traffic["_write_kib_per_launch"] = cs["WRITE_SIZE"]["per_launch"]
     if traffic:
+        import subprocess
+        import time
+        try:
+            traffic["_commit"] = subprocess.run(["git", "log", "-1", "--format=%h"], stdout=subprocess.PIPE,
+                                                stderr=subprocess.DEVNULL, timeout=10).stdout.decode().strip() or None
+        except Exception:
+            traffic["_commit"] = None
+        traffic["_saved"] = time.strftime("%Y-%m-%d %H:%M:%S")
         traffic["_note"] = ("HBM bytes per launch of the dominant kernel, averaged over the launches of "
                             "the bench steps: (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 "
                             "--pmc passes (tools/profile.sh, profiles/%s_pmc.json); FETCH_SIZE doubled "
