@@ -70,8 +70,11 @@ class HipBackend(object):
         self.torch, self.pkg, self.kernel = torch, pkg, kernel
         if not torch.cuda.is_available() or pkg.device_count() < 1:
             raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-        torch.cuda.set_device(local_rank)
-        self.device = torch.device("cuda", local_rank)
+        # (one rank per GPU under the driver; ranks wrap around when a rehearsal runs more ranks than
+        # the box has GPUs, e.g. two gloo ranks on one device)
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
 
     def make_plan(self, shape):
         return self.pkg.Plan(self.pkg.ConvDesc.from_shape(shape), kernel=self.kernel)
@@ -496,6 +499,8 @@ def parse_args(argv=None):
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "tiled"])
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the driver's runs); gloo lets two ranks share one GPU for a rehearsal")
     return ap.parse_args(argv)
 
 
@@ -524,7 +529,10 @@ def main():
     be = HipBackend(pkg, local_rank, kernel)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=be.device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=be.device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     out = run(args, be, pkg, synth, ge.load_oracle, dist if world > 1 else None)
     if out is not None:
         print(json.dumps(out), flush=True)
