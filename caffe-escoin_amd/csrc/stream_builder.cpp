@@ -57,10 +57,13 @@ Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int 
     t.nseg = nseg > 0 ? std::min(nseg, fit) : fit;
     t.bands = 1;
   } else {
+    // bands of equal height: 28 rows on 16 row slots are two bands of 14, not 16 + 12 -- the same
+    // lanes do the same work, but no band stages (or zero-fills) rows past the image, the planes are
+    // smaller (more channels per block) and every tile costs the same
     t.band_mode = true;
-    t.tr = t.rows_per_wg;
     t.nseg = 1;
-    t.bands = (g.OH + t.tr - 1) / t.tr;
+    t.bands = (g.OH + t.rows_per_wg - 1) / t.rows_per_wg;
+    t.tr = (g.OH + t.bands - 1) / t.bands;
   }
   t.plane_rows = t.tr + g.KH - 1;
   t.plane_seg_floats = t.plane_rows * t.RS;
