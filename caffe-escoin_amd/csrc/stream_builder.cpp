@@ -161,21 +161,28 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, 
   }
   Tiling best = tile_for(g, waves_per_wg, lds_budget_bytes, n_cu);
   // A pointwise layer (1x1, no padding) does not care where the rows of an image break: its
-  // H*W pixels are one contiguous run per channel.  When W is not a multiple of 4 the staging
-  // copies (16 bytes per lane) straddle row ends; re-cut the image into rows of W' | H*W that
-  // need the fewest copies (then: best lane use, then longest rows).  Input and output blobs are
-  // the same memory either way.
-  if (g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H && g.OW == g.W &&
-      g.W % 4 != 0) {
+  // H*W pixels are one contiguous run per channel.  These layers are bound by the LDS-DMA fill rate
+  // (DESIGN.md 4.1), and a fill instruction costs the same whether its 16-byte slots carry pixels,
+  // straddle a row end (W not a multiple of 4) or are zero-filled padding (RS > W, band rows past the
+  // image): re-cut the image into rows of W' | H*W whose tiles stage the fewest slots per image
+  // (then: fewest copies that straddle, best lane use, longest rows).  56 x 56 is walked as 49 x 64,
+  // 28 x 28 as 98 x 8, 14 x 14 as 7 x 28: no or 1/8 padding instead of 1/8 .. 1/4.  Input and output
+  // blobs are the same memory either way.
+  if (g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H && g.OW == g.W) {
     const int hw = g.H * g.W;
+    auto slots = [](const Tiling &t) {   // 16-byte LDS slots staged per image and channel
+      return t.band_mode ? (long)t.bands * t.plane_rows * t.S4 : (long)t.plane_rows * t.S4;
+    };
     auto copies = [](const Tiling &t) { return (long)t.H * ((t.W + 3) / 4); };
     auto lane_use = [](const Tiling &t) {
       const double rows = t.band_mode ? (double)t.bands * t.rows_per_wg : (double)t.rows_per_wg;
       const double used = t.band_mode ? (double)t.H : (double)t.H * (t.rows_per_wg / t.H);
       return used * t.W / (rows * t.RS);
     };
+    static const bool no_recut = getenv("ESCOIN_NORECUT") != nullptr;
     for (int w = 1; w <= 256 && w <= hw; ++w) {
       if (hw % w != 0 || w == g.W) continue;
+      if (g.W % 4 == 0 && (w % 4 != 0 || no_recut)) continue;   // never trade aligned rows for straddling ones
       ConvGeom c = g;
       c.W = c.OW = w;
       c.H = c.OH = hw / w;
@@ -183,9 +190,12 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, 
       if (!t.ok) continue;
       bool better = !best.ok;
       if (!better) {
+        const long sa = slots(t), sb = slots(best);
         const long ca = copies(t), cb = copies(best);
         const double ua = lane_use(t), ub = lane_use(best);
-        better = ca < cb || (ca == cb && (ua > ub + 1e-9 || (ua > ub - 1e-9 && t.W > best.W)));
+        const bool tie = ua > ub + 1e-9 || (ua > ub - 1e-9 && t.W > best.W);
+        if (g.W % 4 != 0) better = ca < cb || (ca == cb && tie);   // fewest straddling copies first
+        else better = sa < sb || (sa == sb && tie);                  // aligned rows: fewest staged slots
       }
       if (better) best = t;
     }
