@@ -162,3 +162,23 @@ def test_host_cpu_info_respects_affinity():
     info = bench.host_cpu_info()
     assert 1 <= info["physical_cores"] <= info["hw_threads"] <= len(os.sched_getaffinity(0))
     assert isinstance(info["model"], str)
+
+
+def test_cpu_baseline_leg_fields(monkeypatch):
+    """bench.py's cpu_baseline on two tiny shapes: the reference kernels from oracle/_ref, thread
+    sweep, aligned once outside the timed call, default nest and blocked best-effort leg."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    import bench
+    pkg = ge.load_package()
+    oracle = ge.load_oracle()
+    synth = pkg.synth
+    shapes = [synth.shape("t3", 4, 16, 14, 14, 16, 3, pad=1, sparsity=0.9, count=2),
+              synth.shape("t1", 4, 16, 7, 7, 24, 1, sparsity=0.9)]
+    monkeypatch.setattr(bench, "_HOST_INFO", {"hw_threads": 2, "physical_cores": 2, "model": "test", "cgroup_quota": None})
+    out = bench.cpu_baseline(oracle, synth, shapes, budget_s=0.5)
+    assert out["unit"] == "images/s" and out["value"] > 0 and out["cores"] in (1, 2)
+    assert set(out["thread_sweep"]) == {"1", "2"} and out["single_thread_value"] > 0
+    assert out["kind"] in ("reference", "port") and "sample" in out
+    if out["kind"] == "reference":
+        assert out["best_effort"]["value"] > 0 and "sconv_unit_stride" in out["best_effort"]["kernel"]
