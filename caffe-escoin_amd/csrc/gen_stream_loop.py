@@ -52,6 +52,7 @@ SGPR_LAST = 45
 MAX_SLOTS2 = 6
 ABL = set()                  # timing-only ablations (see main())
 PRIO_HI = 1                  # priority of a wave's even groups (odd groups run at 0)
+PRIO_BASE = 0                # added to both: the second-dispatched half of the workgroup runs one level up
 HOIST = True                 # extract a group's meta / indices ahead of its first FMAs
 
 
@@ -108,7 +109,7 @@ def body2(L, n, p, band):
     # slower all kernel long and every block waits for it.  Alternating priority by group parity
     # lets whichever wave is behind win its even groups.
     if "noprio" not in ABL:
-        A("s_setprio %d" % ((1 - p) * PRIO_HI))
+        A("s_setprio %d" % ((1 - p) * PRIO_HI + PRIO_BASE))
     A("s_set_gpr_idx_idx 0")
     here = 0 if p == 0 else stride             # this group's payload relative to v[VP]
     if n > 3:
@@ -237,8 +238,12 @@ def main():
     out = sys.stdout
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
+    global PRIO_BASE
     emit_macro(out, "ESC2_LOOP_ASM", generate2(False))
     emit_macro(out, "ESC2_LOOP_ASM_BAND", generate2(True))
+    PRIO_BASE = int(os.environ.get("ESC_GEN_PRIO_YOUNG", "2"))
+    emit_macro(out, "ESC2_LOOP_ASM_BAND_YOUNG", generate2(True))
+    PRIO_BASE = 0
     # timing-only ablations (wrong results), compiled in with -DESCOIN_ABLATIONS
     out.write("#ifdef ESCOIN_ABLATIONS\n")
     for name in ("nopk", "noxp"):
