@@ -111,3 +111,45 @@ sys.exit(0 if worst <= 1e-4 else 1)
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert out.returncode == 0, out.stdout.decode()
     assert "REL_ERR" in out.stdout.decode()
+
+
+def test_forward_is_capturable_in_a_hip_graph(pkg, oracle, synth):
+    """escoin_forward only enqueues work on the caller's stream (no allocation, no synchronisation
+    after WeightAlign and the first launch): a whole chain of layer calls can be captured in a HIP
+    graph and replayed, which is how a launch-bound net (LeNet, GoogLeNet's small 1x1 layers) would
+    be driven.  Replays must reproduce the eager results on new inputs."""
+    import torch
+    dev = torch.device("cuda:0")
+    shapes = [synth.lenet_conv2(N=8)[0], synth.googlenet_1x1(N=8)[30], synth.resnet50_3x3(N=8)[3]]
+    plans, xs, tops, biases, ws = [], [], [], [], []
+    for k, s in enumerate(shapes):
+        w, b = synth.pruned_weights(s, 11 + k), synth.bias_vector(s, 21 + k)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+        plan.weight_align(w)
+        plans.append(plan); ws.append((w, b))
+        xs.append(torch.from_numpy(synth.activations(s, 31 + k)).to(dev))
+        biases.append(torch.from_numpy(b).to(dev) if b is not None else None)
+        oh, ow = synth.out_hw(s)
+        tops.append(torch.empty((s.N, s.M, oh, ow), device=dev))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                  # warm-up on the capture stream (first-launch attributes)
+        for p, x, b, t in zip(plans, xs, biases, tops):
+            p.forward(x, b, t)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for p, x, b, t in zip(plans, xs, biases, tops):
+            p.forward(x, b, t)
+    for rep in range(2):
+        for k, (s, x) in enumerate(zip(shapes, xs)):
+            x.copy_(torch.from_numpy(synth.activations(s, 41 + 10 * rep + k)).to(dev))
+        for t in tops:
+            t.fill_(-7.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        for k, s in enumerate(shapes):
+            g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
+            want = oracle.conv_forward(g, xs[k].cpu().numpy(), ws[k][0], ws[k][1], gate=False, threads=4)
+            assert rel_err(tops[k].cpu().numpy(), want) <= 1e-4, (s.name, rep)
+    for p in plans:
+        p.close()
