@@ -241,6 +241,23 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
     }
 
     // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+    // The bias of the lane's 32 rows is fetched in one go (a load per output, each followed by the
+    // compiler's s_waitcnt vmcnt(0), would also wait for the previous STORE every time).
+    float bv[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wm * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        bv[i][reg] = (a.bias && m < a.Mg) ? a.bias[cg * a.Mg + m] : 0.f;
+      }
+    // ... and pinned down here: loads and stores share one counter and complete out of order with
+    // respect to each other, so a load still pending when the stores start makes the compiler put
+    // s_waitcnt vmcnt(0) -- wait for the previous store too -- in front of every one of them
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) asm volatile("" : "+v"(bv[i][reg]));
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int pj = p0 + wn * WN + 32 * j + li;
@@ -254,8 +271,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         for (int reg = 0; reg < 16; ++reg) {
           const int m = m0 + wm * 64 + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
           if (m >= a.Mg) continue;
-          float v = acc[i][j][reg];
-          if (a.bias) v += a.bias[cg * a.Mg + m];
+          float v = acc[i][j][reg] + bv[i][reg];
           if (a.relu) v = fmaxf(v, 0.f);
           obase[(size_t)m * ohw] = v;
         }
