@@ -94,7 +94,7 @@ def prefetch2(L, p_next, p0_off, advance, band):
         A("v_add_u32 v%d, %d, v%d" % (VP, advance, VP))
 
 
-def body2(L, n, p, band):
+def body2(L, n, p, band, label):
     """Group k (phase p).  On entry: X(k), P0(k) were requested at the top of group k-1;
     s[HDR2] = row offset / 32 of group k+1, s[META_P[1-p]] bits 0..7 = accumulator of this group's
     record 0 (left there by group k-1, or by the prologue).  v[VP] is this group's payload address
@@ -104,7 +104,7 @@ def body2(L, n, p, band):
     A = L.append
     stride = 32 if n > 3 else 16
     meta = META_P[p]
-    A("ESC2_L%d_%d_%%=:" % (n, p))
+    A("%s_%%=:" % label)
     # The two waves of a SIMD are arbitrated oldest-first: left alone, the younger one runs ~25 %
     # slower all kernel long and every block waits for it.  Alternating priority by group parity
     # lets whichever wave is behind win its even groups.
@@ -164,13 +164,6 @@ def body2(L, n, p, band):
                     A("s_lshr_b32 s%d, s%d, %d" % (t, src, sh))
                 A("s_set_gpr_idx_idx s%d" % t)
             pk4v(L, r, p)
-    # s_add_u32 x, x, -1: SCC = carry = (x was not 0) = another group follows in this bucket
-    A("s_add_u32 s%d, s%d, -1" % (CNT, CNT))
-    if p == 0:
-        A("s_cbranch_scc0 ESC2_E%d_1_%%=" % (n - 1))     # falls through into phase 1
-    else:
-        A("s_cbranch_scc1 ESC2_L%d_0_%%=" % n)
-        A("s_branch ESC2_E%d_0_%%=" % (n - 1))
 
 
 def generate2(band):
@@ -190,21 +183,39 @@ def generate2(band):
     A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % META_P[1])
     A("s_branch ESC2_E%d_0_%%=" % MAX_SLOTS2)
     for n in range(MAX_SLOTS2, 0, -1):
-        for p in (0, 1):
-            # bucket n: groups [END_(n+1), END_n)
-            A("ESC2_E%d_%d_%%=:" % (n, p))
-            if n == 3 and p == 1:
-                # the last 32-byte group ran in phase 0: v[VP] is its address, the 16-byte
-                # groups' phase 1 expects "previous group = 16 bytes back"
-                A("s_set_gpr_idx_idx 0")
-                A("v_add_u32 v%d, 16, v%d" % (VP, VP))
-            A("s_sub_u32 s%d, s%d, s%d" % (CNT, END0 + n, END0 + n + 1))
-            A("s_cmp_eq_u32 s%d, 0" % CNT)
-            A("s_cbranch_scc1 ESC2_E%d_%d_%%=" % (n - 1, p))
-            A("s_sub_u32 s%d, s%d, 1" % (CNT, CNT))
-            A("s_branch ESC2_L%d_%d_%%=" % (n, p))
-        body2(L, n, 0, band)
-        body2(L, n, 1, band)
+        # bucket n: groups [END_(n+1), END_n).  s[CNT] = groups of the bucket still to run (R).
+        # Groups run in pairs (phase 0, phase 1) with ONE counter update and branch per pair; a
+        # bucket entered in phase 1 runs one group alone first, an odd one out runs alone last
+        # (and hands the next bucket phase 1).
+        A("ESC2_E%d_0_%%=:" % n)
+        A("s_sub_u32 s%d, s%d, s%d" % (CNT, END0 + n, END0 + n + 1))
+        A("s_cmp_eq_u32 s%d, 0" % CNT)
+        A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
+        A("ESC2_C%d_%%=:" % n)
+        A("s_sub_u32 s%d, s%d, 2" % (CNT, CNT))          # SCC = borrow: exactly one group left
+        A("s_cbranch_scc1 ESC2_S%d_%%=" % n)
+        body2(L, n, 0, band, "ESC2_P%d" % n)
+        body2(L, n, 1, band, "ESC2_Q%d" % n)
+        A("s_sub_u32 s%d, s%d, 2" % (CNT, CNT))
+        A("s_cbranch_scc0 ESC2_P%d_%%=" % n)             # another whole pair
+        A("s_cmp_eq_i32 s%d, -2" % CNT)                  # -2: the bucket is done; -1: one group left
+        A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
+        body2(L, n, 0, band, "ESC2_S%d" % n)
+        A("s_branch ESC2_E%d_1_%%=" % (n - 1))
+        A("ESC2_E%d_1_%%=:" % n)
+        if n == 3:
+            # the last 32-byte group ran in phase 0: v[VP] is its address, the 16-byte
+            # groups' phase 1 expects "previous group = 16 bytes back"
+            A("s_set_gpr_idx_idx 0")
+            A("v_add_u32 v%d, 16, v%d" % (VP, VP))
+        A("s_sub_u32 s%d, s%d, s%d" % (CNT, END0 + n, END0 + n + 1))
+        A("s_cmp_eq_u32 s%d, 0" % CNT)
+        A("s_cbranch_scc1 ESC2_E%d_1_%%=" % (n - 1))
+        body2(L, n, 1, band, "ESC2_T%d" % n)
+        A("s_sub_u32 s%d, s%d, 1" % (CNT, CNT))
+        A("s_cmp_eq_u32 s%d, 0" % CNT)
+        A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
+        A("s_branch ESC2_C%d_%%=" % n)
     A("ESC2_E0_0_%=:")
     A("ESC2_E0_1_%=:")
     A("s_setprio 0")
