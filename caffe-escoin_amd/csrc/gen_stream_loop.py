@@ -34,7 +34,7 @@ Operands: %[h0] lead word of the unit, %[h1]..%[h6] = END_6..END_1 (stream_build
 import sys
 
 NV = 32
-VA, VB, VP = 32, 33, 34
+VA, VA2, VP = 32, 33, 34
 XA = [36, 44]
 XB = [40, 48]
 P0 = [52, 56]
@@ -53,7 +53,6 @@ MAX_SLOTS2 = 6
 ABL = set()                  # timing-only ablations (see main())
 PRIO_HI = 1                  # priority of a wave's even groups (odd groups run at 0)
 PRIO_BASE = 0                # added to both: the second-dispatched half of the workgroup runs one level up
-HOIST = True                 # extract a group's meta / indices ahead of its first FMAs
 
 
 def bfe(dst, src, off, width):
@@ -72,35 +71,46 @@ def pk4v(L, r, p):
                  % (acc, acc + 1, pair, pair + 1, x, x + 1, acc, acc + 1, sel, sel))
 
 
-def prefetch2(L, p_next, p0_off, advance, band):
-    """LDS reads of the next group: its two input quads (row offset / 32 in s[HDR2]) and its first
-    payload quad (at v[VP] + p0_off; v[VP] then moves on by `advance` bytes).  Runs with GPR
-    index 0."""
-    A = L.append
+def xreads(L, p_next, areg):
+    """Input quads of a group (tile A, tile B = tile A + 1 KiB) through the address in v[areg]."""
+    if "noxp" in ABL:
+        return
+    L.append("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, areg))
+    L.append("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[p_next], XB[p_next] + 3, areg))
+
+
+def xaddr(L, areg):
+    """LDS address of a group's tile-A quad from its row offset / 32 in s[HDR2].  Needs GPR index 0
+    (a VALU instruction: its VGPR operands are relative like everybody's)."""
     if "noxp" not in ABL:
-        A("v_lshl_add_u32 v%d, s%d, 5, %%[lbA]" % (VA, HDR2))
-        if band:
-            A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
-            A("ds_read_b128 v[%d:%d], v%d offset:1024" % (XB[p_next], XB[p_next] + 3, VA))
-        else:
-            A("v_lshl_add_u32 v%d, s%d, 5, %%[lbB]" % (VB, HDR2))
-            A("ds_read_b128 v[%d:%d], v%d" % (XA[p_next], XA[p_next] + 3, VA))
-            A("ds_read_b128 v[%d:%d], v%d" % (XB[p_next], XB[p_next] + 3, VB))
-    if p0_off:
-        A("ds_read_b128 v[%d:%d], v%d offset:%d" % (P0[p_next], P0[p_next] + 3, VP, p0_off))
+        L.append("v_lshl_add_u32 v%d, s%d, 5, %%[lbA]" % (areg, HDR2))
+
+
+def pread(L, reg, off):
+    if off:
+        L.append("ds_read_b128 v[%d:%d], v%d offset:%d" % (reg, reg + 3, VP, off))
     else:
-        A("ds_read_b128 v[%d:%d], v%d" % (P0[p_next], P0[p_next] + 3, VP))
-    if advance:
-        A("v_add_u32 v%d, %d, v%d" % (VP, advance, VP))
+        L.append("ds_read_b128 v[%d:%d], v%d" % (reg, reg + 3, VP))
 
 
-def body2(L, n, p, band, label):
+LAG = 16     # v[VP] trails the payload address it stands for by one quad (see body2)
+
+
+def body2(L, n, p, label, pair):
     """Group k (phase p).  On entry: X(k), P0(k) were requested at the top of group k-1;
     s[HDR2] = row offset / 32 of group k+1, s[META_P[1-p]] bits 0..7 = accumulator of this group's
-    record 0 (left there by group k-1, or by the prologue).  v[VP] is this group's payload address
-    in phase 0 and the PREVIOUS group's in phase 1: it moves once per two groups, by two strides
-    (both groups have the same stride, 32 bytes for more than 3 records, 16 otherwise -- where
-    the 32-byte groups end in phase 0, the bucket entry ESC2_E3_1 adds the difference)."""
+    record 0 (left there by group k-1, or by the prologue).
+
+    Groups run in pairs (phase 0, phase 1).  Everything of a pair that needs GPR index 0 -- the
+    two address adds and the payload pointer's move -- sits in the phase-0 body, so the phase-1
+    body of a pair switches the index only for its records:
+      v[VP]  = payload address of group k - LAG            at the top of a phase-0 body,
+             = payload address of group k + stride - LAG   at the top of a phase-1 body
+    (stride: 32 bytes for groups of more than 3 records, 16 otherwise; a phase-0 body moves it by
+    two strides once its own reads are out; the lag keeps the second payload quad of a phase-1
+    group at a non-negative offset; where the 32-byte groups end in phase 0, the bucket entry
+    ESC2_E3_1 takes the difference off).  pair = False: the body runs alone (a bucket entered in
+    phase 1, or its odd last group) and computes only its own successor's address."""
     A = L.append
     stride = 32 if n > 3 else 16
     meta = META_P[p]
@@ -110,63 +120,60 @@ def body2(L, n, p, band, label):
     # lets whichever wave is behind win its even groups.
     if "noprio" not in ABL:
         A("s_setprio %d" % ((1 - p) * PRIO_HI + PRIO_BASE))
-    A("s_set_gpr_idx_idx 0")
-    here = 0 if p == 0 else stride             # this group's payload relative to v[VP]
-    if n > 3:
-        A("ds_read_b128 v[%d:%d], v%d offset:%d" % (P1, P1 + 3, VP, here + 16))
-    # group k+1: a whole group of FMAs to land in
-    prefetch2(L, 1 - p, here + stride, 2 * stride if p == 1 else 0, band)
+    if p == 0:
+        A("s_set_gpr_idx_idx 0")
+        if n > 3:
+            pread(L, P1, LAG + 16)
+        # group k+1: a whole group of FMAs to land in
+        xaddr(L, VA)
+        xreads(L, 1, VA)
+        pread(L, P0[1], LAG + stride)
+        A("v_add_u32 v%d, %d, v%d" % (VP, 2 * stride, VP))
+    elif pair:
+        if n > 3:
+            pread(L, P1, 32 - stride)
+        xreads(L, 0, VA2)                   # address left by the phase-0 body
+        pread(L, P0[0], LAG)
+    else:
+        A("s_set_gpr_idx_idx 0")
+        if n > 3:
+            pread(L, P1, 32 - stride)
+        xaddr(L, VA)
+        xreads(L, 0, VA)
+        pread(L, P0[0], LAG)
     if "noxp" in ABL:
         A("s_waitcnt lgkmcnt(%d)" % (2 if n > 3 else 1))
     else:
         A("s_waitcnt lgkmcnt(%d)" % (4 if n > 3 else 3))   # X(k), P0(k) landed
-    if HOIST:
-        # meta of THIS group and the accumulator indices of its records 1, 2 are extracted before
-        # record 0's FMAs: the VALU -> SGPR -> SALU -> M0 chain then runs under those 4 packed FMAs
-        # instead of between record 0 and record 1
-        A("v_readfirstlane_b32 s%d, v%d" % (meta, P0[p]))
-        A("s_lshr_b32 s%d, s%d, 21" % (HDR2, meta))          # row offset / 32 of group k+2
-        for r in range(1, min(n, 3)):
-            t = IXT[r % 2]
-            if r == 2:
-                A(bfe(t, meta, 14, 7))
-            else:
-                A("s_lshr_b32 s%d, s%d, %d" % (t, meta, 7 * r))
-        A("s_set_gpr_idx_idx s%d" % META_P[1 - p])
-        pk4v(L, 0, p)
-        for r in range(1, n):
-            t = IXT[r % 2]
-            if r == 3:
-                A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))
-                A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
-                for r2 in range(4, n):
-                    A("s_lshr_b32 s%d, s%d, %d" % (IXT[r2 % 2], META2, 7 * (r2 - 3)))
-                A("s_set_gpr_idx_idx s%d" % META2)
-            else:
-                A("s_set_gpr_idx_idx s%d" % t)
-            pk4v(L, r, p)
-    else:
-        A("s_set_gpr_idx_idx s%d" % META_P[1 - p])
-        pk4v(L, 0, p)
-        A("v_readfirstlane_b32 s%d, v%d" % (meta, P0[p]))
-        A("s_lshr_b32 s%d, s%d, 21" % (HDR2, meta))          # row offset / 32 of group k+2
-        for r in range(1, n):
-            t = IXT[r % 2]
-            if r == 3:
-                A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))   # the second quad (older than the prefetches) landed
-                A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
-                A("s_set_gpr_idx_idx s%d" % META2)           # record 3: bits 0..7 of meta2 as they are
-            else:
-                src, sh = (meta, 7 * r) if r < 3 else (META2, 7 * (r - 3))
-                if sh == 14 and r < 3:
-                    A(bfe(t, src, 14, 7))                      # bit 21 above it belongs to the row offset
-                else:
-                    A("s_lshr_b32 s%d, s%d, %d" % (t, src, sh))
-                A("s_set_gpr_idx_idx s%d" % t)
-            pk4v(L, r, p)
+    # meta of THIS group and the accumulator indices of its records 1, 2 are extracted before
+    # record 0's FMAs: the VALU -> SGPR -> SALU -> M0 chain then runs under those 4 packed FMAs
+    # instead of between record 0 and record 1
+    A("v_readfirstlane_b32 s%d, v%d" % (meta, P0[p]))
+    A("s_lshr_b32 s%d, s%d, 21" % (HDR2, meta))          # row offset / 32 of group k+2
+    if p == 0 and pair:
+        xaddr(L, VA2)                                    # ... whose reads the phase-1 body issues
+    for r in range(1, min(n, 3)):
+        t = IXT[r % 2]
+        if r == 2:
+            A(bfe(t, meta, 14, 7))
+        else:
+            A("s_lshr_b32 s%d, s%d, %d" % (t, meta, 7 * r))
+    A("s_set_gpr_idx_idx s%d" % META_P[1 - p])
+    pk4v(L, 0, p)
+    for r in range(1, n):
+        t = IXT[r % 2]
+        if r == 3:
+            A("s_waitcnt lgkmcnt(%d)" % (1 if "noxp" in ABL else 3))
+            A("v_readfirstlane_b32 s%d, v%d" % (META2, P1))
+            for r2 in range(4, n):
+                A("s_lshr_b32 s%d, s%d, %d" % (IXT[r2 % 2], META2, 7 * (r2 - 3)))
+            A("s_set_gpr_idx_idx s%d" % META2)
+        else:
+            A("s_set_gpr_idx_idx s%d" % t)
+        pk4v(L, r, p)
 
 
-def generate2(band):
+def generate2():
     L = []
     A = L.append
     A("s_waitcnt lgkmcnt(0)")
@@ -174,8 +181,10 @@ def generate2(band):
     A("s_cbranch_scc1 ESC2_X_%=")
     A("s_mov_b32 s%d, %%[h0]" % META_P[1])                # plays the meta of "group -1"
     A(bfe(HDR2, META_P[1], 8, 11))                       # group 0
-    A("v_mov_b32 v%d, %%[sbase]" % VP)
-    prefetch2(L, 0, 0, 0, band)                          # ... its reads fly under the bookkeeping
+    A("v_add_u32 v%d, %d, %%[sbase]" % (VP, -LAG))
+    xaddr(L, VA)
+    xreads(L, 0, VA)                                     # ... its reads fly under the bookkeeping
+    pread(L, P0[0], LAG)
     for n in range(1, MAX_SLOTS2 + 1):
         A("s_mov_b32 s%d, %%[h%d]" % (END0 + n, 7 - n))
     A("s_mov_b32 s%d, 0" % (END0 + MAX_SLOTS2 + 1))
@@ -194,24 +203,24 @@ def generate2(band):
         A("ESC2_C%d_%%=:" % n)
         A("s_sub_u32 s%d, s%d, 2" % (CNT, CNT))          # SCC = borrow: exactly one group left
         A("s_cbranch_scc1 ESC2_S%d_%%=" % n)
-        body2(L, n, 0, band, "ESC2_P%d" % n)
-        body2(L, n, 1, band, "ESC2_Q%d" % n)
+        body2(L, n, 0, "ESC2_P%d" % n, True)
+        body2(L, n, 1, "ESC2_Q%d" % n, True)
         A("s_sub_u32 s%d, s%d, 2" % (CNT, CNT))
         A("s_cbranch_scc0 ESC2_P%d_%%=" % n)             # another whole pair
         A("s_cmp_eq_i32 s%d, -2" % CNT)                  # -2: the bucket is done; -1: one group left
         A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
-        body2(L, n, 0, band, "ESC2_S%d" % n)
+        body2(L, n, 0, "ESC2_S%d" % n, False)
         A("s_branch ESC2_E%d_1_%%=" % (n - 1))
         A("ESC2_E%d_1_%%=:" % n)
         if n == 3:
-            # the last 32-byte group ran in phase 0: v[VP] is its address, the 16-byte
-            # groups' phase 1 expects "previous group = 16 bytes back"
+            # the last 32-byte group ran in phase 0 and moved v[VP] by two of ITS strides: the
+            # 16-byte groups' phase 1 expects one of theirs
             A("s_set_gpr_idx_idx 0")
-            A("v_add_u32 v%d, 16, v%d" % (VP, VP))
+            A("v_add_u32 v%d, -16, v%d" % (VP, VP))
         A("s_sub_u32 s%d, s%d, s%d" % (CNT, END0 + n, END0 + n + 1))
         A("s_cmp_eq_u32 s%d, 0" % CNT)
         A("s_cbranch_scc1 ESC2_E%d_1_%%=" % (n - 1))
-        body2(L, n, 1, band, "ESC2_T%d" % n)
+        body2(L, n, 1, "ESC2_T%d" % n, False)
         A("s_sub_u32 s%d, s%d, 1" % (CNT, CNT))
         A("s_cmp_eq_u32 s%d, 0" % CNT)
         A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
@@ -243,23 +252,21 @@ def main():
     import os
     if os.environ.get("ESC_GEN_NOPRIO"):
         ABL.add("noprio")
-    global PRIO_HI, HOIST
+    global PRIO_HI
     PRIO_HI = int(os.environ.get("ESC_GEN_PRIO_HI", PRIO_HI))
-    HOIST = os.environ.get("ESC_GEN_HOIST", "1") != "0"
     out = sys.stdout
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
     global PRIO_BASE
-    emit_macro(out, "ESC2_LOOP_ASM", generate2(False))
-    emit_macro(out, "ESC2_LOOP_ASM_BAND", generate2(True))
+    emit_macro(out, "ESC2_LOOP_ASM_BAND", generate2())
     PRIO_BASE = int(os.environ.get("ESC_GEN_PRIO_YOUNG", "2"))
-    emit_macro(out, "ESC2_LOOP_ASM_BAND_YOUNG", generate2(True))
+    emit_macro(out, "ESC2_LOOP_ASM_BAND_YOUNG", generate2())
     PRIO_BASE = 0
     # timing-only ablations (wrong results), compiled in with -DESCOIN_ABLATIONS
     out.write("#ifdef ESCOIN_ABLATIONS\n")
     for name in ("nopk", "noxp"):
         ABL.add(name)
-        emit_macro(out, "ESC2_LOOP_ASM_" + name.upper(), generate2(False))
+        emit_macro(out, "ESC2_LOOP_ASM_" + name.upper(), generate2())
         ABL.discard(name)
     out.write("#endif\n")
     out.write("#define ESC_STREAM_LOOP_CLOBBERS \\\n  ")
