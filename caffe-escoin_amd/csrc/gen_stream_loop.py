@@ -93,27 +93,32 @@ def pread(L, reg, off):
         L.append("ds_read_b128 v[%d:%d], v%d" % (reg, reg + 3, VP))
 
 
-LAG = 16     # v[VP] trails the payload address it stands for by one quad (see body2)
+LAG = 32     # v[VP] trails the payload address it stands for by two quads (see body2)
+QUAD_MAX_N = 3   # buckets of up to this many records also run four groups per counter update
 
 
-def body2(L, n, p, label, pair):
+def body2(L, n, p, label, role):
     """Group k (phase p).  On entry: X(k), P0(k) were requested at the top of group k-1;
     s[HDR2] = row offset / 32 of group k+1, s[META_P[1-p]] bits 0..7 = accumulator of this group's
     record 0 (left there by group k-1, or by the prologue).
 
-    Groups run in pairs (phase 0, phase 1).  Everything of a pair that needs GPR index 0 -- the
-    two address adds and the payload pointer's move -- sits in the phase-0 body, so the phase-1
-    body of a pair switches the index only for its records:
-      v[VP]  = payload address of group k - LAG            at the top of a phase-0 body,
-             = payload address of group k + stride - LAG   at the top of a phase-1 body
-    (stride: 32 bytes for groups of more than 3 records, 16 otherwise; a phase-0 body moves it by
-    two strides once its own reads are out; the lag keeps the second payload quad of a phase-1
-    group at a non-negative offset; where the 32-byte groups end in phase 0, the bucket entry
-    ESC2_E3_1 takes the difference off).  pair = False: the body runs alone (a bucket entered in
-    phase 1, or its odd last group) and computes only its own successor's address."""
+    Groups run four (A B C D) or two (P Q) to a counter update, phases 0 1 0 1.  Everything that
+    needs GPR index 0 -- the address adds and the payload pointer's move -- sits in the phase-0
+    bodies: A / C / P compute their successor's input address before their own records and the
+    address of the group after it once their meta word is in, so B / D / Q switch the index only
+    for their records.  Payload pointer:
+      v[VP]  = payload address of group k - LAG            at the top of A, P, S (phase 0),
+             = payload address of group k + stride - LAG   at the top of Q, T (phase 1)
+    (stride: 32 bytes for groups of more than 3 records, 16 otherwise).  A moves it by four
+    strides, P and S by two, once their own reads are out; B, C, D, Q read at offsets that
+    compensate -- the lag keeps them non-negative.  Where the 32-byte groups end in phase 0, the
+    bucket entry ESC2_E3_1 takes the difference off.  S (a bucket's odd last group) and T (a
+    bucket entered in phase 1) run alone and compute only their own successor's address."""
     A = L.append
     stride = 32 if n > 3 else 16
     meta = META_P[p]
+    assert p == (0 if role in "APCS" else 1)
+    assert n <= QUAD_MAX_N or role in "PQST"
     A("%s_%%=:" % label)
     # The two waves of a SIMD are arbitrated oldest-first: left alone, the younger one runs ~25 %
     # slower all kernel long and every block waits for it.  Alternating priority by group parity
@@ -127,20 +132,22 @@ def body2(L, n, p, label, pair):
         # group k+1: a whole group of FMAs to land in
         xaddr(L, VA)
         xreads(L, 1, VA)
-        pread(L, P0[1], LAG + stride)
-        A("v_add_u32 v%d, %d, v%d" % (VP, 2 * stride, VP))
-    elif pair:
-        if n > 3:
-            pread(L, P1, 32 - stride)
-        xreads(L, 0, VA2)                   # address left by the phase-0 body
-        pread(L, P0[0], LAG)
-    else:
+        pread(L, P0[1], LAG - stride if role == "C" else LAG + stride)
+        if role != "C":
+            A("v_add_u32 v%d, %d, v%d" % (VP, (4 if role == "A" else 2) * stride, VP))
+    elif role == "T":
         A("s_set_gpr_idx_idx 0")
         if n > 3:
-            pread(L, P1, 32 - stride)
+            pread(L, P1, LAG - stride + 16)
         xaddr(L, VA)
         xreads(L, 0, VA)
         pread(L, P0[0], LAG)
+    else:
+        if n > 3:
+            pread(L, P1, LAG - stride + 16)
+        xreads(L, 0, VA2)                   # address left by the phase-0 body
+        pread(L, P0[0], LAG - 2 * stride if role == "B" else LAG)
+    pair = role in "APC"
     if "noxp" in ABL:
         A("s_waitcnt lgkmcnt(%d)" % (2 if n > 3 else 1))
     else:
@@ -201,15 +208,28 @@ def generate2():
         A("s_cmp_eq_u32 s%d, 0" % CNT)
         A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
         A("ESC2_C%d_%%=:" % n)
+        if n <= QUAD_MAX_N:
+            A("s_sub_u32 s%d, s%d, 4" % (CNT, CNT))      # SCC = borrow: fewer than four groups left
+            A("s_cbranch_scc1 ESC2_D%d_%%=" % n)
+            body2(L, n, 0, "ESC2_QA%d" % n, "A")
+            body2(L, n, 1, "ESC2_QB%d" % n, "B")
+            body2(L, n, 0, "ESC2_QC%d" % n, "C")
+            body2(L, n, 1, "ESC2_QD%d" % n, "D")
+            A("s_sub_u32 s%d, s%d, 4" % (CNT, CNT))
+            A("s_cbranch_scc0 ESC2_QA%d_%%=" % n)        # another four
+            A("ESC2_D%d_%%=:" % n)
+            A("s_add_u32 s%d, s%d, 4" % (CNT, CNT))      # 0..3 groups left
+            A("s_cmp_eq_u32 s%d, 0" % CNT)
+            A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
         A("s_sub_u32 s%d, s%d, 2" % (CNT, CNT))          # SCC = borrow: exactly one group left
         A("s_cbranch_scc1 ESC2_S%d_%%=" % n)
-        body2(L, n, 0, "ESC2_P%d" % n, True)
-        body2(L, n, 1, "ESC2_Q%d" % n, True)
+        body2(L, n, 0, "ESC2_P%d" % n, "P")
+        body2(L, n, 1, "ESC2_Q%d" % n, "Q")
         A("s_sub_u32 s%d, s%d, 2" % (CNT, CNT))
         A("s_cbranch_scc0 ESC2_P%d_%%=" % n)             # another whole pair
         A("s_cmp_eq_i32 s%d, -2" % CNT)                  # -2: the bucket is done; -1: one group left
         A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
-        body2(L, n, 0, "ESC2_S%d" % n, False)
+        body2(L, n, 0, "ESC2_S%d" % n, "S")
         A("s_branch ESC2_E%d_1_%%=" % (n - 1))
         A("ESC2_E%d_1_%%=:" % n)
         if n == 3:
@@ -220,7 +240,7 @@ def generate2():
         A("s_sub_u32 s%d, s%d, s%d" % (CNT, END0 + n, END0 + n + 1))
         A("s_cmp_eq_u32 s%d, 0" % CNT)
         A("s_cbranch_scc1 ESC2_E%d_1_%%=" % (n - 1))
-        body2(L, n, 1, "ESC2_T%d" % n, False)
+        body2(L, n, 1, "ESC2_T%d" % n, "T")
         A("s_sub_u32 s%d, s%d, 1" % (CNT, CNT))
         A("s_cmp_eq_u32 s%d, 0" % CNT)
         A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
