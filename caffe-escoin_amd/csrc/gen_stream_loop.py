@@ -52,6 +52,7 @@ SGPR_LAST = 45
 MAX_SLOTS2 = 6
 ABL = set()                  # timing-only ablations (see main())
 PRIO_HI = 1                  # priority of a wave's even groups (odd groups run at 0)
+PRIO_QUADS = True 
 PRIO_BASE = 0                # added to both: the second-dispatched half of the workgroup runs one level up
 
 
@@ -124,7 +125,12 @@ def body2(L, n, p, label, role):
     # slower all kernel long and every block waits for it.  Alternating priority by group parity
     # lets whichever wave is behind win its even groups.
     if "noprio" not in ABL:
-        A("s_setprio %d" % ((1 - p) * PRIO_HI + PRIO_BASE))
+        if PRIO_QUADS and role in "ABCD":
+            # four-group runs: two groups up, two groups down, one switch per two groups
+            if role in "AC":
+                A("s_setprio %d" % ((1 if role == "A" else 0) * PRIO_HI + PRIO_BASE))
+        else:
+            A("s_setprio %d" % ((1 - p) * PRIO_HI + PRIO_BASE))
     if p == 0:
         A("s_set_gpr_idx_idx 0")
         if n > 3:
@@ -272,7 +278,8 @@ def main():
     import os
     if os.environ.get("ESC_GEN_NOPRIO"):
         ABL.add("noprio")
-    global PRIO_HI
+    global PRIO_HI, PRIO_QUADS
+    PRIO_QUADS = os.environ.get("ESC_GEN_PRIO_QUADS", "1") == "1"
     PRIO_HI = int(os.environ.get("ESC_GEN_PRIO_HI", PRIO_HI))
     out = sys.stdout
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
