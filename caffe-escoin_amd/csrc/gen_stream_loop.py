@@ -286,7 +286,7 @@ def main():
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
     global PRIO_BASE
     emit_macro(out, "ESC2_LOOP_ASM_BAND", generate2())
-    PRIO_BASE = int(os.environ.get("ESC_GEN_PRIO_YOUNG", "2"))
+    PRIO_BASE = int(os.environ.get("ESC_GEN_PRIO_YOUNG", "1"))
     emit_macro(out, "ESC2_LOOP_ASM_BAND_YOUNG", generate2())
     PRIO_BASE = 0
     # timing-only ablations (wrong results), compiled in with -DESCOIN_ABLATIONS

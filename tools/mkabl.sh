@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds caffe-escoin_amd/libescoin_abl.so: the library with -DESCOIN_ABLATIONS (in-kernel stamp
+# profile under ESCOIN_PROF=1, timing-only ablations under ESCOIN_DBG).  Not a product build.
+set -e
+cd "$(dirname "$0")/../caffe-escoin_amd/csrc"
+mkdir -p /tmp/abl
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-result -Wno-inline-asm -fvisibility=hidden -DESCOIN_BUILD -DESCOIN_ABLATIONS"
+for s in escoin_capi sconv_generic sconv_tiled dense_mfma sconv_lowered; do
+  /opt/rocm/bin/hipcc $F -c -o /tmp/abl/$s.o $s.hip &
+done
+/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -fvisibility=hidden -I. -c -o /tmp/abl/stream_builder.o stream_builder.cpp &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libescoin_abl.so /tmp/abl/*.o
+ls -la ../libescoin_abl.so
