@@ -124,7 +124,7 @@ def body2(L, n, p, label, role):
     # The two waves of a SIMD are arbitrated oldest-first: left alone, the younger one runs ~25 %
     # slower all kernel long and every block waits for it.  Alternating priority by group parity
     # lets whichever wave is behind win its even groups.
-    if "noprio" not in ABL:
+    if "noprio" not in ABL and PRIO_HI != 0:
         if PRIO_QUADS and role in "ABCD":
             # four-group runs: two groups up, two groups down, one switch per two groups
             if role in "AC":
@@ -203,6 +203,8 @@ def generate2():
     A("s_mov_b32 s%d, 0" % (END0 + MAX_SLOTS2 + 1))
     A("s_lshr_b32 s%d, s%d, 21" % (HDR2, META_P[1]))     # group 1
     A("s_set_gpr_idx_on s%d, gpr_idx(SRC2,DST)" % META_P[1])
+    if "noprio" not in ABL and PRIO_HI == 0:
+        A("s_setprio %d" % PRIO_BASE)                    # a constant level: set once
     A("s_branch ESC2_E%d_0_%%=" % MAX_SLOTS2)
     for n in range(MAX_SLOTS2, 0, -1):
         # bucket n: groups [END_(n+1), END_n).  s[CNT] = groups of the bucket still to run (R).
@@ -287,8 +289,11 @@ def main():
     global PRIO_BASE
     emit_macro(out, "ESC2_LOOP_ASM_BAND", generate2())
     PRIO_BASE = int(os.environ.get("ESC_GEN_PRIO_YOUNG", "1"))
+    old_hi = PRIO_HI
+    PRIO_HI = int(os.environ.get("ESC_GEN_PRIO_YOUNG_HI", 0))
     emit_macro(out, "ESC2_LOOP_ASM_BAND_YOUNG", generate2())
     PRIO_BASE = 0
+    PRIO_HI = old_hi
     # timing-only ablations (wrong results), compiled in with -DESCOIN_ABLATIONS
     out.write("#ifdef ESCOIN_ABLATIONS\n")
     for name in ("nopk", "noxp"):
