@@ -340,58 +340,73 @@ def main():
                     "v_mov_b32 %%2, v%d" % (C0 + 2), "v_mov_b32 %%3, v%d" % (C0 + 3),
                 ]
                 emit_macro(out, "ESC_EPI3%s_%d_%d" % ("M" if masked else "", tile, g), lines)
-    # ESC_EPI3S_<tile>: the whole 3x3 / pad 1 epilogue of a tile in one block, for outputs whose
-    # rows are whole quads (OW % 4 == 0): per channel the shift-and-sum of the three classes in
-    # place, bias and ReLU when bit 0 / bit 1 of %[flags] say so, and ONE global_store_dwordx4 from
-    # the accumulator registers through an SGPR base that moves on by one channel plane
-    # (%[ostr] bytes) -- no copies into compiler registers, no per-channel address arithmetic on
-    # the vector side.  %[voff] = the lane's byte offset from %[base] (channel m0 of the wave),
-    # %[ok] = lanes that own an output quad, %[bias] lane g = bias of channel m0 + g, %[gcount] =
-    # channels of this wave (1..8).  s[32:37] scratch.
+    # ESC_EPI3S_<tile>_<r>: the whole 3x3 / pad 1 epilogue of a tile in one block, r = OW % 4: per
+    # channel the shift-and-sum of the three classes in place, bias and ReLU when bit 0 / bit 1
+    # of %[flags] say so, and the stores straight from the accumulator registers through an SGPR
+    # base that moves on by one channel plane (%[ostr] bytes) -- no copies into compiler
+    # registers, no per-channel address arithmetic on the vector side.  Lanes in %[ok] own a whole
+    # output quad (one global_store_dwordx4; dword alignment is all a global store needs); for
+    # r != 0 the lanes in %[okp] own the row's last, partial quad: they store r elements, and the
+    # two class values of theirs that a STORED output takes from beyond the row (kc = 2 at column
+    # OW for their own last output, kc = 0 at the quad's last column for the first output of the
+    # row that follows in the lane order: neighbouring rows' data, not padding) are multiplied by
+    # %[pm] (0 in those lanes, 1 elsewhere) first.  %[voff] = the lane's byte offset from %[base] (channel m0 of
+    # the wave), %[bias] lane g = bias of channel m0 + g, %[gcount] = channels of this wave
+    # (1..8).  s[32:37] scratch.
     for tile, base in ((0, ACC_A), (1, ACC_B)):
-        lines = ["s_mov_b64 s[32:33], exec", "s_mov_b64 s[34:35], %[base]"]
-        ng = NACC_TILE // 12
-        for g in range(ng):
-            L0 = base + 12 * g
-            C0 = L0 + 4
-            R0 = L0 + 8
-            lines += [
-                "v_add_f32 v%d, v%d, v%d" % (C0 + 0, C0 + 0, R0 + 1),
-                "v_add_f32 v%d, v%d, v%d" % (C0 + 1, C0 + 1, L0 + 0),
-                "v_add_f32 v%d, v%d, v%d" % (C0 + 1, C0 + 1, R0 + 2),
-                "v_add_f32 v%d, v%d, v%d" % (C0 + 2, C0 + 2, L0 + 1),
-                "v_add_f32 v%d, v%d, v%d" % (C0 + 2, C0 + 2, R0 + 3),
-                "v_add_f32 v%d, v%d, v%d" % (C0 + 3, C0 + 3, L0 + 2),
-                "v_add_f32_dpp v%d, v%d, v%d row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-                % (C0 + 0, L0 + 3, C0 + 0),
-                "v_add_f32_dpp v%d, v%d, v%d row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-                % (C0 + 3, R0 + 0, C0 + 3),
-                "s_bitcmp1_b32 %[flags], 0",
-                "s_cbranch_scc0 ESC_EB%d_%d_%%=" % (tile, g),
-                "v_readlane_b32 s36, %%[bias], %d" % g,
-                "s_nop 1",
-                "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0, C0 + 1, C0, C0 + 1),
-                "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0 + 2, C0 + 3, C0 + 2, C0 + 3),
-                "ESC_EB%d_%d_%%=:" % (tile, g),
-                "s_bitcmp1_b32 %[flags], 1",
-                "s_cbranch_scc0 ESC_ER%d_%d_%%=" % (tile, g),
-            ]
-            lines += ["v_max_f32 v%d, 0, v%d" % (C0 + e, C0 + e) for e in range(4)]
-            lines += [
-                "ESC_ER%d_%d_%%=:" % (tile, g),
-                "s_mov_b64 exec, %[ok]",
-                "global_store_dwordx4 %%[voff], v[%d:%d], s[34:35]" % (C0, C0 + 3),
-                "s_mov_b64 exec, s[32:33]",
-            ]
-            if g + 1 < ng:
+        for r in range(4):
+            lines = ["s_mov_b64 s[32:33], exec", "s_mov_b64 s[34:35], %[base]"]
+            ng = NACC_TILE // 12
+            for g in range(ng):
+                L0 = base + 12 * g
+                C0 = L0 + 4
+                R0 = L0 + 8
+                if r:
+                    lines.append("v_mul_f32 v%d, v%d, %%[pm]" % (R0 + r, R0 + r))
+                    lines.append("v_mul_f32 v%d, v%d, %%[pm]" % (L0 + 3, L0 + 3))
                 lines += [
-                    "s_add_u32 s34, s34, %[ostr]",
-                    "s_addc_u32 s35, s35, 0",
-                    "s_cmp_eq_u32 %%[gcount], %d" % (g + 1),
-                    "s_cbranch_scc1 ESC_EX%d_%%=" % tile,
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 0, C0 + 0, R0 + 1),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 1, C0 + 1, L0 + 0),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 1, C0 + 1, R0 + 2),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 2, C0 + 2, L0 + 1),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 2, C0 + 2, R0 + 3),
+                    "v_add_f32 v%d, v%d, v%d" % (C0 + 3, C0 + 3, L0 + 2),
+                    "v_add_f32_dpp v%d, v%d, v%d row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                    % (C0 + 0, L0 + 3, C0 + 0),
+                    "v_add_f32_dpp v%d, v%d, v%d row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                    % (C0 + 3, R0 + 0, C0 + 3),
+                    "s_bitcmp1_b32 %[flags], 0",
+                    "s_cbranch_scc0 ESC_EB%d_%d_%%=" % (tile, g),
+                    "v_readlane_b32 s36, %%[bias], %d" % g,
+                    "s_nop 1",
+                    "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0, C0 + 1, C0, C0 + 1),
+                    "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0 + 2, C0 + 3, C0 + 2, C0 + 3),
+                    "ESC_EB%d_%d_%%=:" % (tile, g),
+                    "s_bitcmp1_b32 %[flags], 1",
+                    "s_cbranch_scc0 ESC_ER%d_%d_%%=" % (tile, g),
                 ]
-        lines.append("ESC_EX%d_%%=:" % tile)
-        emit_macro(out, "ESC_EPI3S_%d" % tile, lines)
+                lines += ["v_max_f32 v%d, 0, v%d" % (C0 + e, C0 + e) for e in range(4)]
+                lines += [
+                    "ESC_ER%d_%d_%%=:" % (tile, g),
+                    "s_mov_b64 exec, %[ok]",
+                    "global_store_dwordx4 %%[voff], v[%d:%d], s[34:35]" % (C0, C0 + 3),
+                ]
+                if r:
+                    lines.append("s_mov_b64 exec, %[okp]")
+                    if r == 1:
+                        lines.append("global_store_dword %%[voff], v%d, s[34:35]" % C0)
+                    else:
+                        lines.append("global_store_dwordx%d %%[voff], v[%d:%d], s[34:35]" % (r, C0, C0 + r - 1))
+                lines.append("s_mov_b64 exec, s[32:33]")
+                if g + 1 < ng:
+                    lines += [
+                        "s_add_u32 s34, s34, %[ostr]",
+                        "s_addc_u32 s35, s35, 0",
+                        "s_cmp_eq_u32 %%[gcount], %d" % (g + 1),
+                        "s_cbranch_scc1 ESC_EX%d_%%=" % tile,
+                    ]
+            lines.append("ESC_EX%d_%%=:" % tile)
+            emit_macro(out, "ESC_EPI3S_%d_%d" % (tile, r), lines)
     out.write("#define ESC_EPI3S_CLOBBERS \"memory\", \"scc\", \"s32\", \"s33\", \"s34\", \"s35\", \"s36\", \"s37\", ")
     out.write(", ".join('\"v%d\"' % i for i in range(ACC_A, 256)))
     out.write("\n")

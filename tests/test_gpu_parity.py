@@ -242,6 +242,31 @@ def test_bias_null_relu_and_partial_batch(pkg, oracle, synth, torch_cuda):
         plan.close()
 
 
+def test_tile_store_epilogue_bias_relu_ragged_channels(pkg, oracle, synth, torch_cuda):
+    """3x3 / pad 1 layers whose rows are whole quads take the one-block asm epilogue (stores straight
+    from the accumulators): bias, ReLU, both, neither; channel counts that leave the last wave with
+    fewer than 8 channels; widths with and without padding quads; batches that leave tile slots empty."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    S = synth.shape
+    k = 0
+    for (N, Cc, H, W, M) in [(3, 16, 8, 8, 20), (2, 12, 28, 28, 13), (2, 8, 56, 56, 9), (5, 24, 12, 16, 64), (1, 8, 4, 32, 7)]:
+        s = S("epi%d" % k, N, Cc, H, W, M, 3, pad=1, sparsity=0.8)
+        w, b, x = synth.pruned_weights(s, 700 + k), synth.bias_vector(s, 710 + k), synth.activations(s, 720 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, 3, 3, 1, 1)
+        xd = torch.from_numpy(x).to(dev)
+        for relu in (False, True):
+            for tb in (0, 256):
+                plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=pkg.KERNEL_TILED, tiling_batch=tb)
+                plan.weight_align(w)
+                for bias in (None, b):
+                    got = plan.forward(xd, None if bias is None else torch.from_numpy(bias).to(dev)).cpu().numpy()
+                    want = oracle.conv_forward(g, x, w, bias, relu=relu, gate=False)
+                    assert rel_err(got, want) <= TOL, (s.name, relu, tb, bias is not None, rel_err(got, want))
+                plan.close()
+        k += 1
+
+
 def test_weight_align_from_device_and_csr_roundtrip(pkg, oracle, synth, torch_cuda):
     torch = torch_cuda
     s = synth.alexnet(N=2)[0]                       # group = 2
