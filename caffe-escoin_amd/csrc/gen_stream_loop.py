@@ -407,6 +407,39 @@ def main():
                     ]
             lines.append("ESC_EX%d_%%=:" % tile)
             emit_macro(out, "ESC_EPI3S_%d_%d" % (tile, r), lines)
+    # ESC_EPI1S_<tile>: the same for pointwise layers (one class per channel, up to 24 channels per
+    # wave, nothing to shift) whose output rows are whole quads
+    for tile, base in ((0, ACC_A), (1, ACC_B)):
+        lines = ["s_mov_b64 s[32:33], exec", "s_mov_b64 s[34:35], %[base]", "s_mov_b64 exec, %[ok]"]
+        ng = NACC_TILE // 4
+        for g in range(ng):
+            C0 = base + 4 * g
+            lines += [
+                "s_bitcmp1_b32 %[flags], 0",
+                "s_cbranch_scc0 ESC_PB%d_%d_%%=" % (tile, g),
+                "v_readlane_b32 s36, %%[bias], %d" % g,
+                "s_nop 1",
+                "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0, C0 + 1, C0, C0 + 1),
+                "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0 + 2, C0 + 3, C0 + 2, C0 + 3),
+                "ESC_PB%d_%d_%%=:" % (tile, g),
+                "s_bitcmp1_b32 %[flags], 1",
+                "s_cbranch_scc0 ESC_PR%d_%d_%%=" % (tile, g),
+            ]
+            lines += ["v_max_f32 v%d, 0, v%d" % (C0 + e, C0 + e) for e in range(4)]
+            lines += [
+                "ESC_PR%d_%d_%%=:" % (tile, g),
+                "global_store_dwordx4 %%[voff], v[%d:%d], s[34:35]" % (C0, C0 + 3),
+            ]
+            if g + 1 < ng:
+                lines += [
+                    "s_add_u32 s34, s34, %[ostr]",
+                    "s_addc_u32 s35, s35, 0",
+                    "s_cmp_eq_u32 %%[gcount], %d" % (g + 1),
+                    "s_cbranch_scc1 ESC_PX%d_%%=" % tile,
+                ]
+        lines.append("ESC_PX%d_%%=:" % tile)
+        lines.append("s_mov_b64 exec, s[32:33]")
+        emit_macro(out, "ESC_EPI1S_%d" % tile, lines)
     out.write("#define ESC_EPI3S_CLOBBERS \"memory\", \"scc\", \"s32\", \"s33\", \"s34\", \"s35\", \"s36\", \"s37\", ")
     out.write(", ".join('\"v%d\"' % i for i in range(ACC_A, 256)))
     out.write("\n")
