@@ -10,8 +10,11 @@ cd "$GRAFT_REPO_ROOT"
 OUT=${PROF_OUT:-gpurun_out}/prof_${TAG}_${WL}
 rm -rf $OUT; mkdir -p $OUT
 ARGS="bench.py --workload $WL --steps 5 --warmup 2 --no-cpu"
+# (PMC passes: inputs generated with one call per layer, see bench.py device_images)
+export ESCOIN_BENCH_BULK_INPUTS=0
 # the kernel-stats pass runs bench.py with its default step counts (the command the driver times)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --workload $WL --no-cpu > $OUT/bench_stats.json 2> $OUT/bench_stats.log
+export ESCOIN_BENCH_BULK_INPUTS=1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > /dev/null 2> $OUT/pmc_write.log
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > /dev/null 2> $OUT/pmc_sq.log
