@@ -62,6 +62,8 @@ static void free_device(escoin_plan *p) {
   if (p->d_stream) (void)hipFree(p->d_stream);
   if (p->d_unit_hdr) (void)hipFree(p->d_unit_hdr);
   p->d_unit_hdr = nullptr;
+  if (p->d_chan) (void)hipFree(p->d_chan);
+  p->d_chan = nullptr;
   if (p->d_col) (void)hipFree(p->d_col);
   p->d_col = nullptr;
   p->col_bytes = 0;

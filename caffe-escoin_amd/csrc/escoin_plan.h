@@ -81,6 +81,7 @@ struct escoin_plan {
   escoin::TiledConfig tiled;
   unsigned *d_stream = nullptr;   // unit bodies of the weight stream (stream_builder.h)
   unsigned *d_unit_hdr = nullptr; // 8 dwords per (conv group, oc group, ic block)
+  unsigned *d_chan = nullptr;     // slot -> output channel (WeightStream::chan)
   size_t stream_words = 0;
 
   // dense fallback (fp32 MFMA implicit GEMM), chosen per conv group: bit g of dense_mask = group g

@@ -388,20 +388,24 @@ def main():
                 lines += ["v_max_f32 v%d, 0, v%d" % (C0 + e, C0 + e) for e in range(4)]
                 lines += [
                     "ESC_ER%d_%d_%%=:" % (tile, g),
+                    # the channel in slot g (channels may have been re-dealt over the waves): its plane
+                    "v_readlane_b32 s36, %%[chanv], %d" % g,
+                    "s_nop 0",
+                    "s_mul_i32 s36, s36, %[ostr]",
+                    "s_add_u32 s38, s34, s36",
+                    "s_addc_u32 s39, s35, 0",
                     "s_mov_b64 exec, %[ok]",
-                    "global_store_dwordx4 %%[voff], v[%d:%d], s[34:35]" % (C0, C0 + 3),
+                    "global_store_dwordx4 %%[voff], v[%d:%d], s[38:39]" % (C0, C0 + 3),
                 ]
                 if r:
                     lines.append("s_mov_b64 exec, %[okp]")
                     if r == 1:
-                        lines.append("global_store_dword %%[voff], v%d, s[34:35]" % C0)
+                        lines.append("global_store_dword %%[voff], v%d, s[38:39]" % C0)
                     else:
-                        lines.append("global_store_dwordx%d %%[voff], v[%d:%d], s[34:35]" % (r, C0, C0 + r - 1))
+                        lines.append("global_store_dwordx%d %%[voff], v[%d:%d], s[38:39]" % (r, C0, C0 + r - 1))
                 lines.append("s_mov_b64 exec, s[32:33]")
                 if g + 1 < ng:
                     lines += [
-                        "s_add_u32 s34, s34, %[ostr]",
-                        "s_addc_u32 s35, s35, 0",
                         "s_cmp_eq_u32 %%[gcount], %d" % (g + 1),
                         "s_cbranch_scc1 ESC_EX%d_%%=" % tile,
                     ]
@@ -440,7 +444,7 @@ def main():
         lines.append("ESC_PX%d_%%=:" % tile)
         lines.append("s_mov_b64 exec, s[32:33]")
         emit_macro(out, "ESC_EPI1S_%d" % tile, lines)
-    out.write("#define ESC_EPI3S_CLOBBERS \"memory\", \"scc\", \"s32\", \"s33\", \"s34\", \"s35\", \"s36\", \"s37\", ")
+    out.write("#define ESC_EPI3S_CLOBBERS \"memory\", \"scc\", \"s32\", \"s33\", \"s34\", \"s35\", \"s36\", \"s37\", \"s38\", \"s39\", ")
     out.write(", ".join('\"v%d\"' % i for i in range(ACC_A, 256)))
     out.write("\n")
     # ESC_READ_QUAD_<tile>_<q>: asm text moving accumulator quad q of a tile into %0..%3

@@ -214,6 +214,97 @@ struct Group {
 };
 }  // namespace
 
+std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const std::vector<int> &rowptr,
+                                       const std::vector<int> &colidx) {
+  const int G = t.G, n_ocg = t.n_ocg, Mg = g.Mg;
+  std::vector<uint32_t> slot(static_cast<size_t>(n_ocg) * G);
+  for (int o = 0; o < n_ocg; ++o)
+    for (int gl = 0; gl < G; ++gl) slot[(size_t)o * G + gl] = (uint32_t)std::min(o * G + gl, Mg - 1);
+  static const bool enabled = !(getenv("ESCOIN_BALANCE") && atoi(getenv("ESCOIN_BALANCE")) == 0);
+  if (!enabled || g.KW == 1 || t.oc_waves < 2 || Mg < 2 * G) return slot;
+  constexpr double kGroupCost = 12.3, kRecordCost = 5.75;
+  const int rows_per_blk = t.icb * g.KH;
+  const int words = (rows_per_blk + 63) / 64;
+  const int nb = t.n_icb;
+  // per channel and block: which input rows it touches, how many nonzeros
+  std::vector<uint64_t> mask((size_t)Mg * nb * words, 0ull);
+  std::vector<int> recs((size_t)Mg * nb, 0);
+  for (int m = 0; m < Mg; ++m)
+    for (int j = rowptr[m]; j < rowptr[m + 1]; ++j) {
+      const int col = colidx[j];
+      const int kr = (col / g.KW) % g.KH, ic = col / (g.KW * g.KH);
+      const int b = ic / t.icb, r = (ic - b * t.icb) * g.KH + kr;
+      mask[((size_t)m * nb + b) * words + (r >> 6)] |= 1ull << (r & 63);
+      ++recs[(size_t)m * nb + b];
+    }
+  auto count_of = [&](int o) { return std::max(0, std::min(G, Mg - o * G)); };
+  std::vector<uint64_t> acc(words);
+  auto wave_cost = [&](int o, int b) {      // cost of oc-group o in block b under `slot`
+    std::fill(acc.begin(), acc.end(), 0ull);
+    int rc = 0;
+    const int n = count_of(o);
+    for (int gl = 0; gl < n; ++gl) {
+      const int m = (int)slot[(size_t)o * G + gl];
+      const uint64_t *mk = &mask[((size_t)m * nb + b) * words];
+      for (int w = 0; w < words; ++w) acc[w] |= mk[w];
+      rc += recs[(size_t)m * nb + b];
+    }
+    int rows = 0;
+    for (int w = 0; w < words; ++w) rows += __builtin_popcountll(acc[w]);
+    return kGroupCost * rows + kRecordCost * rc;
+  };
+  for (int blk0 = 0; blk0 < n_ocg; blk0 += t.oc_waves) {          // one workgroup column
+    const int nw = std::min(t.oc_waves, n_ocg - blk0);
+    if (nw < 2) continue;
+    std::vector<double> cost((size_t)nw * nb);
+    for (int w = 0; w < nw; ++w)
+      for (int b = 0; b < nb; ++b) cost[(size_t)w * nb + b] = wave_cost(blk0 + w, b);
+    auto objective_with = [&](int wa, const std::vector<double> &ca, int wb, const std::vector<double> &cb) {
+      double tot = 0;
+      for (int b = 0; b < nb; ++b) {
+        double mx = 0;
+        for (int w = 0; w < nw; ++w) {
+          const double c = w == wa ? ca[b] : w == wb ? cb[b] : cost[(size_t)w * nb + b];
+          mx = std::max(mx, c);
+        }
+        tot += mx;
+      }
+      return tot;
+    };
+    std::vector<double> none;
+    double best = objective_with(-1, none, -1, none);
+    std::vector<double> ca(nb), cb(nb);
+    for (int pass = 0; pass < 3; ++pass) {
+      bool improved = false;
+      for (int wa = 0; wa < nw; ++wa)
+        for (int ga = 0; ga < count_of(blk0 + wa); ++ga)
+          for (int wb = wa + 1; wb < nw; ++wb)
+            for (int gb = 0; gb < count_of(blk0 + wb); ++gb) {
+              uint32_t &sa = slot[(size_t)(blk0 + wa) * G + ga], &sb = slot[(size_t)(blk0 + wb) * G + gb];
+              std::swap(sa, sb);
+              for (int b = 0; b < nb; ++b) {
+                ca[b] = wave_cost(blk0 + wa, b);
+                cb[b] = wave_cost(blk0 + wb, b);
+              }
+              const double obj = objective_with(wa, ca, wb, cb);
+              if (obj < best * (1.0 - 1e-9)) {
+                best = obj;
+                for (int b = 0; b < nb; ++b) {
+                  cost[(size_t)wa * nb + b] = ca[b];
+                  cost[(size_t)wb * nb + b] = cb[b];
+                }
+                improved = true;
+              } else {
+                std::swap(sa, sb);
+              }
+            }
+      if (!improved) break;
+    }
+  }
+  // slots past the last channel of a partly filled oc-group repeat a valid channel
+  return slot;
+}
+
 WeightStream build_stream(const ConvGeom &g, const Tiling &t,
                             const std::vector<std::vector<int>> &rowptr,
                             const std::vector<std::vector<int>> &colidx,
@@ -228,14 +319,19 @@ WeightStream build_stream(const ConvGeom &g, const Tiling &t,
     std::memcpy(&u, &v, 4);
     return u;
   };
+  ws.chan.reserve((size_t)g.group * t.n_ocg * t.G);
+  for (int cg = 0; cg < g.group; ++cg) {
+    const std::vector<uint32_t> sl = balance_channels(g, t, rowptr[cg], colidx[cg]);
+    ws.chan.insert(ws.chan.end(), sl.begin(), sl.end());
+  }
   for (int cg = 0; cg < g.group; ++cg)
     for (int ocg = 0; ocg < t.n_ocg; ++ocg)
       for (int blk = 0; blk < t.n_icb; ++blk) {
         for (auto &r : rows) r.clear();
         const int ic_lo = blk * t.icb, ic_hi = std::min(g.Cg, ic_lo + t.icb);
         for (int gl = 0; gl < t.G; ++gl) {
-          const int m = ocg * t.G + gl;
-          if (m >= g.Mg) break;
+          if (ocg * t.G + gl >= g.Mg) break;       // (slots are filled in order; the rest are empty)
+          const int m = (int)ws.chan[((size_t)cg * t.n_ocg + ocg) * t.G + gl];
           for (int j = rowptr[cg][m]; j < rowptr[cg][m + 1]; ++j) {
             const int col = colidx[cg][j];
             const int kc = col % g.KW, kr = (col / g.KW) % g.KH, ic = col / (g.KW * g.KH);

@@ -54,6 +54,18 @@ static int run(const Case &cs) {
     }
   }
   WeightStream ws2 = build_stream(g, t, rp, ci, va);
+  // the slot -> channel table deals every channel of a conv group exactly once
+  if (ws2.chan.size() != (size_t)g.group * t.n_ocg * t.G) { printf("chan table has the wrong size\n"); return 3; }
+  for (int cgi = 0; cgi < g.group; ++cgi) {
+    std::vector<int> seen(g.Mg, 0);
+    for (int s = 0; s < t.n_ocg * t.G; ++s) {
+      const uint32_t c = ws2.chan[(size_t)cgi * t.n_ocg * t.G + s];
+      if ((int)c >= g.Mg) { printf("chan table entry out of range\n"); return 3; }
+      if (s < g.Mg) seen[c]++;
+    }
+    for (int m = 0; m < g.Mg; ++m)
+      if (seen[m] != 1) { printf("channel %d dealt %d times\n", m, seen[m]); return 3; }
+  }
   if (stage_bytes_for(ws2.max_body_bytes) > 16384) { printf("staging area too large\n"); return 5; }
 
   // reference dense conv (double)
@@ -180,8 +192,8 @@ static int run(const Case &cs) {
           const int ocg = ocblk * t.oc_waves + ow_;
           if (ocg >= t.n_ocg) continue;
           for (int gl = 0; gl < t.G; ++gl) {
-            const int m = ocg * t.G + gl;
-            if (m >= g.Mg) break;
+            if (ocg * t.G + gl >= g.Mg) break;
+            const int m = (int)ws2.chan[((size_t)cg * t.n_ocg + ocg) * t.G + gl];   // channel in this slot
             const int oc = cg * g.Mg + m;
             for (int tl = 0; tl < 2; ++tl)
               for (int lane = 0; lane < 64; ++lane) {

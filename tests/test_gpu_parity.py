@@ -267,6 +267,33 @@ def test_tile_store_epilogue_bias_relu_ragged_channels(pkg, oracle, synth, torch
         k += 1
 
 
+def test_uneven_channel_densities(pkg, oracle, synth, torch_cuda):
+    """A pruned model's output channels differ in density (here 0 .. 60 % nonzeros, some channels
+    empty): WeightAlign re-deals them over the waves block by block (stream_builder.h
+    balance_channels), so slot order != channel order in the stream, the bias lanes and the store
+    addresses.  3x3 (asm epilogue) and 5x5 (C++ epilogue), bias + ReLU, two conv groups."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    S = synth.shape
+    rng = np.random.RandomState(7)
+    for k, (N, Cc, H, W, M, K, pad, group) in enumerate([(3, 32, 14, 14, 96, 3, 1, 1), (2, 24, 28, 28, 64, 3, 1, 1),
+                                                          (2, 16, 13, 13, 48, 5, 2, 2), (2, 64, 7, 7, 128, 3, 1, 1)]):
+        s = S("uneven%d" % k, N, Cc, H, W, M, K, pad=pad, group=group, sparsity=0.0)
+        w = synth.pruned_weights(s, 800 + k)
+        keep = rng.uniform(0.0, 0.6, size=M)
+        keep[rng.randint(0, M, size=3)] = 0.0
+        mask = rng.uniform(size=w.shape) < keep[:, None, None, None]
+        w = (w * mask).astype(np.float32)
+        b, x = synth.bias_vector(s, 810 + k), synth.activations(s, 820 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, K, K, pad, pad, 1, 1, 1, 1, group)
+        want = oracle.conv_forward(g, x, w, b, relu=True, gate=False)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=True), kernel=pkg.KERNEL_TILED, tiling_batch=256)
+        plan.weight_align(w)
+        got = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+        assert rel_err(got, want) <= TOL, (s.name, rel_err(got, want))
+        plan.close()
+
+
 def test_weight_align_from_device_and_csr_roundtrip(pkg, oracle, synth, torch_cuda):
     torch = torch_cuda
     s = synth.alexnet(N=2)[0]                       # group = 2
