@@ -411,6 +411,73 @@ def main():
                     ]
             lines.append("ESC_EX%d_%%=:" % tile)
             emit_macro(out, "ESC_EPI3S_%d_%d" % (tile, r), lines)
+    # ESC_EPI5S_<tile>_<r>: the same for 5x5 / pad 2 (five classes per channel, 4 channels per
+    # wave): out[e] = sum over kc of class_kc[e + kc - 2], accumulated in place on class 2; positions
+    # -2, -1 come from the left neighbour's elements 2, 3 and positions 4, 5 from the right
+    # neighbour's 0, 1 through DPP.  In the lanes of a row's partial last quad (r != 0) every class
+    # value at an element >= r is multiplied by %[pm] = 0 first (they hold a neighbouring row's
+    # data, and stored outputs two columns away reach them).
+    for tile, base in ((0, ACC_A), (1, ACC_B)):
+        for r in range(4):
+            lines = ["s_mov_b64 s[32:33], exec", "s_mov_b64 s[34:35], %[base]"]
+            ng = NACC_TILE // 20
+            for g in range(ng):
+                cls = [base + 20 * g + 4 * kc for kc in range(5)]
+                C0 = cls[2]
+                if r:
+                    for kc in (0, 1, 3, 4):
+                        for e in range(r, 4):
+                            lines.append("v_mul_f32 v%d, v%d, %%[pm]" % (cls[kc] + e, cls[kc] + e))
+                for e in range(4):
+                    for kc in (0, 1, 3, 4):
+                        pos = e + kc - 2
+                        if 0 <= pos <= 3:
+                            lines.append("v_add_f32 v%d, v%d, v%d" % (C0 + e, C0 + e, cls[kc] + pos))
+                for e in range(4):
+                    for kc in (0, 1, 3, 4):
+                        pos = e + kc - 2
+                        if pos < 0:
+                            lines.append("v_add_f32_dpp v%d, v%d, v%d row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                         % (C0 + e, cls[kc] + pos + 4, C0 + e))
+                        elif pos > 3:
+                            lines.append("v_add_f32_dpp v%d, v%d, v%d row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                         % (C0 + e, cls[kc] + pos - 4, C0 + e))
+                lines += [
+                    "s_bitcmp1_b32 %[flags], 0",
+                    "s_cbranch_scc0 ESC_FB%d_%d_%%=" % (tile, g),
+                    "v_readlane_b32 s36, %%[bias], %d" % g,
+                    "s_nop 1",
+                    "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0, C0 + 1, C0, C0 + 1),
+                    "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0 + 2, C0 + 3, C0 + 2, C0 + 3),
+                    "ESC_FB%d_%d_%%=:" % (tile, g),
+                    "s_bitcmp1_b32 %[flags], 1",
+                    "s_cbranch_scc0 ESC_FR%d_%d_%%=" % (tile, g),
+                ]
+                lines += ["v_max_f32 v%d, 0, v%d" % (C0 + e, C0 + e) for e in range(4)]
+                lines += [
+                    "ESC_FR%d_%d_%%=:" % (tile, g),
+                    "v_readlane_b32 s36, %%[chanv], %d" % g,
+                    "s_nop 0",
+                    "s_mul_i32 s36, s36, %[ostr]",
+                    "s_add_u32 s38, s34, s36",
+                    "s_addc_u32 s39, s35, 0",
+                    "s_mov_b64 exec, %[ok]",
+                    "global_store_dwordx4 %%[voff], v[%d:%d], s[38:39]" % (C0, C0 + 3),
+                ]
+                if r:
+                    lines.append("s_mov_b64 exec, %[okp]")
+                    if r == 1:
+                        lines.append("global_store_dword %%[voff], v%d, s[38:39]" % C0)
+                    else:
+                        lines.append("global_store_dwordx%d %%[voff], v[%d:%d], s[38:39]" % (r, C0, C0 + r - 1))
+                lines.append("s_mov_b64 exec, s[32:33]")
+                if g + 1 < ng:
+                    lines += [
+                        "s_cmp_eq_u32 %%[gcount], %d" % (g + 1),
+                        "s_cbranch_scc1 ESC_FX%d_%%=" % tile,
+                    ]
+            lines.append("ESC_FX%d_%%=:" % tile)
+            emit_macro(out, "ESC_EPI5S_%d_%d" % (tile, r), lines)
     # ESC_EPI1S_<tile>: the same for pointwise layers (one class per channel, up to 24 channels per
     # wave, nothing to shift) whose output rows are whole quads
     for tile, base in ((0, ACC_A), (1, ACC_B)):

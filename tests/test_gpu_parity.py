@@ -250,10 +250,14 @@ def test_tile_store_epilogue_bias_relu_ragged_channels(pkg, oracle, synth, torch
     dev = torch.device("cuda:0")
     S = synth.shape
     k = 0
-    for (N, Cc, H, W, M) in [(3, 16, 8, 8, 20), (2, 12, 28, 28, 13), (2, 8, 56, 56, 9), (5, 24, 12, 16, 64), (1, 8, 4, 32, 7)]:
-        s = S("epi%d" % k, N, Cc, H, W, M, 3, pad=1, sparsity=0.8)
+    cases = [(3, 16, 8, 8, 20, 3), (2, 12, 28, 28, 13, 3), (2, 8, 56, 56, 9, 3), (5, 24, 12, 16, 64, 3), (1, 8, 4, 32, 7, 3)]
+    # 5x5 / pad 2: every OW % 4, rows whose partial quad is / is not the last one of the LDS row
+    cases += [(2, 8, 27, 27, 10, 5), (2, 8, 9, 13, 6, 5), (3, 8, 6, 16, 5, 5), (2, 8, 7, 30, 9, 5), (2, 6, 10, 22, 4, 5),
+              (2, 6, 5, 21, 7, 5), (1, 4, 6, 64, 3, 5), (2, 6, 8, 31, 8, 5), (2, 6, 8, 15, 8, 5)]
+    for (N, Cc, H, W, M, K) in cases:
+        s = S("epi%d" % k, N, Cc, H, W, M, K, pad=K // 2, sparsity=0.8)
         w, b, x = synth.pruned_weights(s, 700 + k), synth.bias_vector(s, 710 + k), synth.activations(s, 720 + k)
-        g = oracle.geom(s.C, s.H, s.W, s.M, 3, 3, 1, 1)
+        g = oracle.geom(s.C, s.H, s.W, s.M, K, K, K // 2, K // 2)
         xd = torch.from_numpy(x).to(dev)
         for relu in (False, True):
             for tb in (0, 256):
