@@ -212,6 +212,7 @@ def generate2():
         # bucket entered in phase 1 runs one group alone first, an odd one out runs alone last
         # (and hands the next bucket phase 1).
         A("ESC2_E%d_0_%%=:" % n)
+        dma_site(L, n, 0)
         A("s_sub_u32 s%d, s%d, s%d" % (CNT, END0 + n, END0 + n + 1))
         A("s_cmp_eq_u32 s%d, 0" % CNT)
         A("s_cbranch_scc1 ESC2_E%d_0_%%=" % (n - 1))
@@ -240,6 +241,7 @@ def generate2():
         body2(L, n, 0, "ESC2_S%d" % n, "S")
         A("s_branch ESC2_E%d_1_%%=" % (n - 1))
         A("ESC2_E%d_1_%%=:" % n)
+        dma_site(L, n, 1)
         if n == 3:
             # the last 32-byte group ran in phase 0 and moved v[VP] by two of ITS strides: the
             # 16-byte groups' phase 1 expects one of theirs
@@ -260,6 +262,44 @@ def generate2():
     A("ESC2_X_%=:")
     A("s_waitcnt lgkmcnt(0)")
     return L
+
+
+DMA_SITES = (6, 5, 4, 3, 2)  # bucket entries that put plane DMA of the next block in flight
+DMA_PER_SITE = 2
+DMA_ON = False               # generate2() emits the sites (the *_DMA copies of the loop)
+
+
+def dma_site(L, n, p):
+    """At the entry of bucket n: up to DMA_PER_SITE of the LDS-DMA instructions this wave still owes
+    the fill in flight (%[nch] of them: LDS address %[dst], channel as the scalar offset %[soff],
+    the lane's table entry %[tv]; both move on by this wave's stride).  Issued in a burst after
+    the barrier an LDS-DMA instruction holds its wave for ~100 cycles (issue is throttled by
+    completion); one or two at a time among the FMAs cost 5-20 cycles each
+    (tools/probes/probe_ldsdma.hip).  The sites fall at about 0, 8, 21, 42 and 69 % of the walk at
+    the benchmarked densities.  M0 is the LDS address of a DMA instruction: it is put back to
+    "index 0, SRC2 | DST relative" afterwards (every body sets the index before its first indexed
+    instruction; no VALU instruction executes in between).  Kept to the bare instructions, and to
+    a kernel of its own (escoin_sconv_tiled_dma_kernel): versions issuing whole channel planes of
+    1-4 pieces under lane masks, or switching index mode off and on around the DMA, lost more in
+    the sites than they won, and the sites' operands and checks cost a layer that cannot use them
+    1.5-3 %."""
+    if n not in DMA_SITES or not DMA_ON:
+        return
+    A = L.append
+    A("s_cmp_eq_u32 %[nch], 0")
+    A("s_cbranch_scc1 ESC2_NS%d_%d_%%=" % (n, p))
+    for k in range(DMA_PER_SITE):
+        if k:
+            A("s_cmp_eq_u32 %[nch], 0")
+            A("s_cbranch_scc1 ESC2_NR%d_%d_%%=" % (n, p))
+        A("s_mov_b32 m0, %[dst]")
+        A("s_add_u32 %[dst], %[dst], %[dstep]")
+        A("s_sub_u32 %[nch], %[nch], 1")
+        A("buffer_load_dwordx4 %[tv], %[rsrc], %[soff] offen lds")
+        A("s_add_u32 %[soff], %[soff], %[sstep]")
+    A("ESC2_NR%d_%d_%%=:" % (n, p))
+    A("s_mov_b32 m0, 0xc000")
+    A("ESC2_NS%d_%d_%%=:" % (n, p))
 
 
 def clobbers():
@@ -287,13 +327,17 @@ def main():
     out.write("// GENERATED by gen_stream_loop.py -- do not edit.\n")
     out.write("#define ESC_NV %d\n#define ESC_NACC_TILE %d\n" % (NV, NACC_TILE))
     global PRIO_BASE
-    emit_macro(out, "ESC2_LOOP_ASM_BAND", generate2())
-    PRIO_BASE = int(os.environ.get("ESC_GEN_PRIO_YOUNG", "1"))
-    old_hi = PRIO_HI
-    PRIO_HI = int(os.environ.get("ESC_GEN_PRIO_YOUNG_HI", 0))
-    emit_macro(out, "ESC2_LOOP_ASM_BAND_YOUNG", generate2())
-    PRIO_BASE = 0
-    PRIO_HI = old_hi
+    global DMA_ON
+    for DMA_ON in (False, True):
+        sfx = "_DMA" if DMA_ON else ""
+        emit_macro(out, "ESC2_LOOP_ASM_BAND" + sfx, generate2())
+        PRIO_BASE = int(os.environ.get("ESC_GEN_PRIO_YOUNG", "1"))
+        old_hi = PRIO_HI
+        PRIO_HI = int(os.environ.get("ESC_GEN_PRIO_YOUNG_HI", 0))
+        emit_macro(out, "ESC2_LOOP_ASM_BAND_YOUNG" + sfx, generate2())
+        PRIO_BASE = 0
+        PRIO_HI = old_hi
+    DMA_ON = False
     # timing-only ablations (wrong results), compiled in with -DESCOIN_ABLATIONS
     out.write("#ifdef ESCOIN_ABLATIONS\n")
     for name in ("nopk", "noxp"):
