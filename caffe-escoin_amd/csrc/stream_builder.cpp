@@ -68,6 +68,15 @@ Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int 
   t.plane_rows = t.tr + g.KH - 1;
   t.plane_seg_floats = t.plane_rows * t.RS;
   t.plane_ch_floats = t.nseg * t.plane_seg_floats;
+  // A channel plane just short of 64 / 128 / 256 quads is padded up to it (13 x 13 with its halo:
+  // 120 -> 128 quads): whole 1 KiB DMA instructions per channel, a wave's instructions an
+  // arithmetic progression with one table entry -- the fast issue path and, for 3x3 layers, the
+  // kernel that issues them from inside the stream walk.  (The padding quads are filled like any
+  // row past the image: zeros, or rows of the image nobody reads.)
+  for (int p2 = 64; p2 <= 256; p2 *= 2) {
+    const int q = t.plane_ch_floats / 4;
+    if (q < p2 && q * 16 >= p2 * 15) t.plane_ch_floats = p2 * 4;
+  }
   const int per_ch = t.plane_ch_floats * 4;
   // (row offsets travel as offset / 32 in 11-bit fields of the stream: 64 KiB per plane buffer)
   lds_budget_bytes = std::min(lds_budget_bytes, 64 * 1024);
