@@ -20,14 +20,18 @@ Design notes (all measured on MI355X, tools/probes/):
 
 Register contract with sconv_tiled.hip (C++ compiled with amdgpu_num_vgpr(NV): the compiler
 never touches v[NV..255]):
-    v32,v33   LDS addresses of the next group's input quads      v34  LDS address of the
-    v[36:51]  input quads: phase p -> A: v[36+8p..], B: v[40+8p..]      current group's payload
+    v32,v33   LDS addresses of the input quads of the next group / the one after it (tile A;
+              tile B = tile A + 1 KiB)               v34  payload pointer (trails by LAG bytes)
+    v[36:51]  input quads: phase p -> A: v[36+8p..], B: v[40+8p..]
     v[52:55], v[56:59]  first payload quad, two phases            v[60:63] second payload quad
     v[64:159] tile-A accumulators, v[160:255] tile-B accumulators (same index + 96)
     s[32:45]  scratch owned by the asm
 Operands: %[h0] lead word of the unit, %[h1]..%[h6] = END_6..END_1 (stream_builder.h),
-%[lbA]/%[lbB] the lane's LDS byte addresses of its two quads (plane row 0, channel 0),
-%[sbase] LDS byte address of the wave's staging area.
+%[lbA] the lane's LDS byte address of its tile-A quad (plane row 0, channel 0; %[lbB] is unused),
+%[sbase] LDS byte address of the first quad in the wave's staging area.  The *_DMA copies of the
+loop (escoin_sconv_tiled_dma_kernel) also take the plane-DMA operands of dma_site().
+Groups run four / two to a counter update (body2), priorities per half of the workgroup
+(PRIO_*), tile epilogues as single asm blocks (ESC_EPI3S / EPI5S / EPI1S, main()).
 
     python gen_stream_loop.py > stream_loop_asm.inc
 """
@@ -52,8 +56,8 @@ SGPR_LAST = 45
 MAX_SLOTS2 = 6
 ABL = set()                  # timing-only ablations (see main())
 PRIO_HI = 1                  # priority of a wave's even groups (odd groups run at 0)
-PRIO_QUADS = True 
-PRIO_BASE = 0                # added to both: the second-dispatched half of the workgroup runs one level up
+PRIO_QUADS = True            # four-group runs: one priority switch per two groups
+PRIO_BASE = 0                # added to both (the second-dispatched half of the workgroup: constant level 1, see main())
 
 
 def bfe(dst, src, off, width):
