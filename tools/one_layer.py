@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Times ONE ResNet-50 3x3 layer shape back to back (no other kernel in between): separates a
+kernel's own speed from what its neighbours in the bench step do to the chip's clocks.
+    ESCOIN_LIB=... python tools/one_layer.py res5 [launches]
+"""
+import importlib
+import os
+import sys
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("caffe-escoin_amd")
+synth = pkg.synth
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "res5"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    shapes = {s.name.split("_")[0]: s for s in synth.resnet50_3x3(N=256, sparsity=0.9)}
+    s = shapes[which]
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    plan.weight_align(synth.pruned_weights(s, 1))
+    dev = torch.device("cuda:0")
+    x = torch.rand((s.N, s.C, s.H, s.W), device=dev) * 2 - 1
+    for _ in range(20):
+        y = plan.forward(x, None)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for rep in range(5):
+        a.record()
+        for _ in range(n):
+            y = plan.forward(x, None)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / n * 1e3)
+    print("%s %-40s %s us per launch (5 x %d launches): %s" % (os.path.basename(os.environ.get("ESCOIN_LIB", "default")), plan.kernel_name, which, n, " ".join("%.1f" % t for t in ts)))
+
+
+if __name__ == "__main__":
+    main()
