@@ -121,6 +121,12 @@ def test_config_layers_at_config_batch_vs_oracle(pkg, oracle, synth, torch_cuda,
         err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k)
         assert "tiled" in name, (s.name, name)
         assert err <= TOL, "%s @N=%d via %s: %g" % (s.name, s.N, name, err)
+        # the 3x3 layers whose planes are whole 1 KiB pieces take the instantiation that issues the
+        # next block's plane DMA from inside the stream walk
+        if s.name.startswith(("res3", "res4", "alex_conv3", "alex_conv4", "alex_conv5")):
+            assert "tiled_dma_kernel" in name, (s.name, name)
+        if s.name.startswith(("res2", "res5", "alex_conv2")):
+            assert "tiled_dma_kernel" not in name, (s.name, name)
 
 
 def test_per_group_dense_selection_and_conv_mode_0(pkg, oracle, synth, torch_cuda):
