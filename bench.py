@@ -474,7 +474,9 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         traffic = int(traffic / tw)
     t_bind = sum(max(synth.algorithmic_bytes(s, per_gpu_batch) / (HBM_PEAK_GBS * 1e9),
                      synth.flops(s, per_gpu_batch) / (FP32_VECTOR_TFLOPS * 1e12)) * s.count for s in shapes)
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1),
+    # (one name per rocprofv3 row: the family's instantiations, most launches first)
+    dom_label = " + ".join(sorted(dom["inst"], key=lambda k: -dom["inst"][k]["launches"]))
+    roofline = {"bound": "hbm", "kernel": dom_label, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_provenance": provenance,
                 "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
