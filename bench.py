@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# Default (timed steps, warm-up steps) per workload: about 40 ms of warm-up and 200 ms timed.  With 5
+# warm-up steps the chip had not settled (clocks, caches): 20 timed steps of the AlexNet set
+# (0.7 ms each) read 12 % slower than 300, of the ResNet set 1 %.
+DEFAULT_STEPS = {"resnet50": (100, 20), "alexnet": (300, 60), "googlenet": (150, 30), "lenet": (2000, 500)}
 FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector) = peak FP32 (matrix)
 
 
@@ -520,8 +524,8 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per workload, see DEFAULT_STEPS)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: per workload)")
     ap.add_argument("--workload", default="resnet50")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=None,
@@ -532,7 +536,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the driver's runs); gloo lets two ranks share one GPU for a rehearsal")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    k, w = DEFAULT_STEPS.get(args.workload, (100, 20))
+    if args.steps is None:
+        args.steps = k
+    if args.warmup is None:
+        args.warmup = w
+    return args
 
 
 def main():
