@@ -25,7 +25,7 @@ def main():
     budget = float(os.environ.get("SWEEP_CPU_BUDGET", "8"))
     print("# Conv-layer forward images/s vs weight sparsity, one MI355X, fp32 (tools/sparsity_sweep.py)\n")
     print("Each row is one `bench.py --workload W --sparsity S` run (same contract as the bench line: inputs "
-          "resident in HBM, 20 timed steps, parity of the timed outputs against the oracle in the last column). "
+          "resident in HBM, default step counts, parity of the timed outputs against the oracle in the last column). "
           "`kernel mix` = what KERNEL_AUTO chose per conv group (dense fp32 MFMA above 50 % density). CPU = the "
           "reference's sconv on the box's host cores (default loop nest / its register-blocked kernel), "
           "bounded sample.\n")
