@@ -36,6 +36,21 @@ def main():
         b.record()
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) / n * 1e3)
+    if os.environ.get("ONE_LAYER_GAPS"):
+        # the same launches with the chip idle in between (host sleep): is the back-to-back rate
+        # limited by sustained power / clocks?
+        import time
+        gaps = []
+        for _ in range(40):
+            time.sleep(float(os.environ["ONE_LAYER_GAPS"]) * 1e-3)
+            a.record()
+            y = plan.forward(x, None)
+            b.record()
+            torch.cuda.synchronize()
+            gaps.append(a.elapsed_time(b) * 1e3)
+        gaps.sort()
+        print("   single launches %s ms apart: median %.1f us, min %.1f, max %.1f" %
+              (os.environ["ONE_LAYER_GAPS"], gaps[len(gaps) // 2], gaps[0], gaps[-1]))
     print("%s %-40s %s us per launch (5 x %d launches): %s" % (os.path.basename(os.environ.get("ESCOIN_LIB", "default")), plan.kernel_name, which, n, " ".join("%.1f" % t for t in ts)))
 
 
