@@ -1,0 +1,81 @@
+// WeightAlign's channel deal (stream_builder.h balance_channels) on seeded random and deliberately
+// uneven CSR patterns: the slot -> channel table must be a permutation of the group's channels, and
+// the modelled block-by-block cost (sum over blocks of the slowest wave of each workgroup column)
+// must not be worse than with the channels in their natural order.  Prints one line per case.
+#include "stream_builder.h"
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+using namespace escoin;
+
+static double objective(const ConvGeom &g, const Tiling &t, const std::vector<int> &rowptr,
+                        const std::vector<int> &colidx, const std::vector<uint32_t> &slot) {
+  const int rows_per_blk = t.icb * g.KH;
+  double sum_max = 0;
+  for (int blk0 = 0; blk0 < t.n_ocg; blk0 += t.oc_waves)
+    for (int b = 0; b < t.n_icb; ++b) {
+      double mx = 0;
+      for (int w = blk0; w < std::min(t.n_ocg, blk0 + t.oc_waves); ++w) {
+        std::vector<char> rows(rows_per_blk, 0);
+        int rc = 0;
+        for (int gl = 0; gl < t.G && w * t.G + gl < g.Mg; ++gl) {
+          const int m = (int)slot[(size_t)w * t.G + gl];
+          for (int j = rowptr[m]; j < rowptr[m + 1]; ++j) {
+            const int col = colidx[j], kr = (col / g.KW) % g.KH, ic = col / (g.KW * g.KH);
+            if (ic / t.icb != b) continue;
+            rows[(ic - b * t.icb) * g.KH + kr] = 1;
+            ++rc;
+          }
+        }
+        int nr = 0;
+        for (char c : rows) nr += c;
+        mx = std::max(mx, 12.3 * nr + 5.75 * rc);
+      }
+      sum_max += mx;
+    }
+  return sum_max;
+}
+
+int main() {
+  struct Case { int C, H, M, K; double dens; bool uneven; };
+  const Case cases[] = {{64, 56, 64, 3, 0.1, false},  {256, 14, 256, 3, 0.1, false}, {512, 7, 512, 3, 0.1, false},
+                        {256, 13, 384, 3, 0.2, false}, {96, 14, 200, 3, 0.15, true},  {48, 27, 128, 5, 0.2, true},
+                        {32, 9, 20, 3, 0.3, true}};
+  int bad = 0;
+  for (const Case &c : cases) {
+    ConvGeom g{};
+    g.N = 256; g.C = c.C; g.H = c.H; g.W = c.H; g.M = c.M; g.KH = c.K; g.KW = c.K;
+    g.pad_h = c.K / 2; g.pad_w = c.K / 2; g.group = 1; g.Cg = c.C; g.Mg = c.M; g.OH = c.H; g.OW = c.H;
+    g.density = (float)c.dens;
+    const Tiling t = choose_tiling(g, 8, 64 * 1024, 256);
+    if (!t.ok) { printf("no tiling\n"); return 2; }
+    std::mt19937 rng(7 + c.M);
+    std::uniform_real_distribution<double> u(0, 1);
+    std::vector<int> rowptr(c.M + 1, 0), colidx;
+    for (int m = 0; m < c.M; ++m) {
+      const double d = c.uneven ? c.dens * 3.0 * u(rng) * (m % 7 == 0 ? 0.0 : 1.0) : c.dens;
+      for (int k = 0; k < c.C * c.K * c.K; ++k)
+        if (u(rng) < d) colidx.push_back(k);
+      rowptr[m + 1] = (int)colidx.size();
+    }
+    std::vector<uint32_t> ident((size_t)t.n_ocg * t.G);
+    for (size_t s = 0; s < ident.size(); ++s) ident[s] = (uint32_t)std::min<size_t>(s, c.M - 1);
+    const std::vector<uint32_t> slot = balance_channels(g, t, rowptr, colidx);
+    if (slot.size() != ident.size()) { printf("wrong table size\n"); return 2; }
+    std::vector<int> seen(c.M, 0);
+    for (int s = 0; s < c.M; ++s) {
+      if ((int)slot[s] >= c.M) { printf("entry out of range\n"); return 2; }
+      seen[slot[s]]++;
+    }
+    for (int m = 0; m < c.M; ++m)
+      if (seen[m] != 1) { printf("channel %d dealt %d times\n", m, seen[m]); return 2; }
+    const double o0 = objective(g, t, rowptr, colidx, ident), o1 = objective(g, t, rowptr, colidx, slot);
+    printf("C%d %dx%d M%d K%d dens %.2f %s: G=%d n_icb=%d  cost natural %.0f  dealt %.0f  (%.1f %%)\n", c.C, c.H, c.H,
+           c.M, c.K, c.dens, c.uneven ? "uneven" : "uniform", t.G, t.n_icb, o0, o1, 100.0 * (o1 / o0 - 1.0));
+    if (o1 > o0 * (1.0 + 1e-9)) ++bad;
+  }
+  if (bad) { printf("%d case(s) got worse\n", bad); return 1; }
+  printf("all cases OK\n");
+  return 0;
+}

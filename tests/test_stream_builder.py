@@ -19,3 +19,17 @@ def test_stream_and_tiling_against_cpu_emulation(tmp_path):
     assert out.returncode == 0, text
     assert "all cases OK" in text
     assert text.count("rel_err=") == 28
+
+
+def test_channel_deal_is_a_permutation_and_never_worse(tmp_path):
+    """balance_channels (WeightAlign): slot -> channel table is a permutation; the modelled cost of
+    the slowest wave per block, summed, does not exceed the natural order's (tests/cpp/balance_check.cpp)."""
+    exe = str(tmp_path / "balance_check")
+    csrc = os.path.join(ROOT, "caffe-escoin_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + csrc, "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "balance_check.cpp"),
+                           os.path.join(csrc, "stream_builder.cpp")])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text
+    assert "all cases OK" in text
