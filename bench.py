@@ -7,7 +7,12 @@
 A "step" is one pass of the hot path (escoin_forward, the Forward_gpu drop-in) over one batch
 of synthetic input for every conv layer of the workload.  Default workload = BASELINE.json's
 configs[2]: the 16 ResNet-50 3x3 branch2b layers at 90 % weight sparsity, batch 256 per GPU,
-fp32.  For N > 1 the driver launches one process per GPU (torch.distributed.run); the batch
+fp32.  For N > 1 there is one process per GPU: either the caller starts them (`python -m
+torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, RANK / WORLD_SIZE in the
+environment) or `python bench.py --gpus N` starts them ITSELF -- the way the reference's one
+command starts a worker per GPU (tools/caffe.cpp:254-256, parallel.cpp:328-358): the parent
+spawns torch.distributed.run as a child process before anything has touched the GPU, never
+initialises HIP itself, relays rank 0's JSON line and exits with the children's code.  The batch
 dimension is sharded, the sparse weights are broadcast once from rank 0 over RCCL, and no
 collective sits in the timed region.  Default = weak scaling (256 images per GPU);
 `--global-batch 2048` = BASELINE.json's configs[3] as strong scaling (2048 / N images per GPU).
@@ -148,24 +153,26 @@ def build_layers(be, pkg, synth, shapes, rank, world):
 
 
 def last_layer_of_shape(layers):
+    """{shape index: index (in `layers`) of the last layer of that shape}"""
     last = {}
-    for entry in layers:
-        last[entry[3]] = entry
+    for li, entry in enumerate(layers):
+        last[entry[3]] = li
     return last
 
 
 def parity_check(be, oracle, synth, layers, bottoms, tops, images_per_shape=3):
-    """After the timed region: tops[si] holds the output of the LAST layer of shape si.  Images
+    """After the timed region: tops[li] holds the output of layer li; the LAST layer of every shape is checked.  Images
     {0, N/2, N-1} of this rank's shard are recomputed by the CPU oracle from the same inputs and
     weights (regenerated from their seeds) -- the checker, never the thing measured."""
     torch = be.torch
     worst = 0.0
-    for si, (s, plan, bias, _, lid) in sorted(last_layer_of_shape(layers).items()):
-        n = bottoms[si].shape[0]
+    for si, li in sorted(last_layer_of_shape(layers).items()):
+        s, plan, bias, _, lid = layers[li]
+        n = bottoms[li].shape[0]
         imgs = sorted(set([0, n // 2, n - 1]))[:images_per_shape]
         idx = torch.tensor(imgs, device=be.device)
-        x = bottoms[si][idx].cpu().numpy()
-        got = tops[si][idx].cpu().numpy()
+        x = bottoms[li][idx].cpu().numpy()
+        got = tops[li][idx].cpu().numpy()
         g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
                         s.dil_h, s.dil_w, s.group)
         w = synth.pruned_weights(s, layer_weight_seed(lid))
@@ -185,9 +192,10 @@ def cross_rank_check(be, dist, synth, layers, shapes, tops, rank, world, g0_of_r
     torch = be.torch
     worst = 0.0
     n_max = max(n_of_rank)
-    for si, (s, plan, bias, _, lid) in sorted(last_layer_of_shape(layers).items()):
+    for si, li in sorted(last_layer_of_shape(layers).items()):
+        s, plan, bias, _, lid = layers[li]
         sums = torch.zeros(n_max, device=be.device, dtype=torch.float64)
-        sums[:tops[si].shape[0]] = tops[si].double().sum(dim=(1, 2, 3))
+        sums[:tops[li].shape[0]] = tops[li].double().sum(dim=(1, 2, 3))
         gathered = [torch.zeros_like(sums) for _ in range(world)]
         dist.all_gather(gathered, sums)
         if rank != 0:
@@ -359,6 +367,10 @@ def traffic_with_provenance(workload, kernel_name):
                    "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE"}
 
 
+def test_be(be):
+    return be.name != "hip"
+
+
 def run(args, be, pkg, synth, oracle_loader, dist=None):
     torch = be.torch
     rank = int(os.environ.get("RANK", "0"))
@@ -385,9 +397,17 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     layers, t_bcast = build_layers(be, pkg, synth, shapes, rank, world)
 
     # ---- synthetic activations resident in HBM (image k seeded by its GLOBAL index) -----------
-    bottoms, tops = [], []
+    # Every LAYER has its own bottom / top pair (layers of one shape get copies of the same
+    # synthetic batch): consecutive launches of one shape must not find their input in the 256 MB
+    # Infinity Cache because the previous launch read the same buffer (res4's six launches read
+    # 51 MB each).  A step touches 2.8 GB on the ResNet set, so every launch reads from HBM.
+    shape_bottoms = []
     for si, s in enumerate(shapes):
-        bottoms.append(device_images(be, s, si, g0_of_rank[rank], per_gpu_batch))
+        shape_bottoms.append(device_images(be, s, si, g0_of_rank[rank], per_gpu_batch))
+    bottoms, tops, used = [], [], set()
+    for (s, plan, bias, si, lid) in layers:
+        bottoms.append(shape_bottoms[si] if si not in used else shape_bottoms[si].clone())
+        used.add(si)
         oh, ow = synth.out_hw(s)
         tops.append(torch.empty((per_gpu_batch, s.M, oh, ow), device=be.device))
     be.synchronize()
@@ -398,7 +418,7 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         if events is not None:
             events[0].record()
         for li, (s, plan, bias, si, lid) in enumerate(layers):
-            plan.forward(bottoms[si], bias, tops[si])
+            plan.forward(bottoms[li], bias, tops[li])
             if events is not None:
                 events[li + 1].record()
 
@@ -453,7 +473,7 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         seen.setdefault(si, []).append(layer_ms[li])
     for si, s in enumerate(shapes):
         m = float(np.mean(seen[si]))
-        name = last_layer_of_shape(layers)[si][1].kernel_name
+        name = layers[last_layer_of_shape(layers)[si]][1].kernel_name
         byt, flo = synth.algorithmic_bytes(s, per_gpu_batch), synth.flops(s, per_gpu_batch)
         t_hbm, t_fma = byt / (HBM_PEAK_GBS * 1e9), flo / (FP32_VECTOR_TFLOPS * 1e12)
         per_layer.append({"layer": s.name, "count": s.count, "us": round(m * 1e3, 1),
@@ -499,7 +519,8 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     value = global_batch / (ms_per_step * 1e-3)
     out = {
         "metric": "conv-layer fwd images/sec", "value": round(value, 1), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -508,6 +529,9 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
                    "global_batch": global_batch, "layers_per_step": len(layers),
                    "kernel": args.kernel, "parallelism": "batch-sharded x%d" % world,
                    "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None},
+        "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None,
+        "backend": be.name, "dist_backend": (be.dist_backend if test_be(be) else args.dist_backend) if world > 1 else None,
+        "buffers": "one bottom/top pair per layer (no launch re-reads the previous launch's input)",
         "parity_max_rel_err": float("%.3g" % parity),
         "cross_rank_checksum_rel_diff": None if cross is None else float("%.3g" % cross),
         "roofline": roofline,
@@ -545,8 +569,69 @@ def parse_args(argv=None):
     return args
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` with no RANK / WORLD_SIZE in the environment: start the N ranks.
+
+    The reference's one command starts a worker per GPU itself (tools/caffe.cpp:254-256 ->
+    P2PSync::Run, parallel.cpp:328-358).  Here the workers are processes: this parent starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD, before
+    torch or HIP has been imported here -- it never touches the GPU and replaces no process --,
+    forwards the children's stderr, relays the one JSON line of rank 0 and returns the worst exit
+    code (no JSON line from a run that claims success is a failure too)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    log("bench.py: starting %d ranks: %s" % (n_ranks, " ".join(cmd)))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    line = None
+    for raw in child.stdout:
+        text = raw.decode("utf-8", "replace").rstrip("\n")
+        if text.startswith("{") and '"metric"' in text:
+            try:
+                json.loads(text)
+                line = text
+                continue
+            except ValueError:
+                pass
+        log(text)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("bench.py: the ranks exited 0 without a JSON line")
+        rc = 1
+    return rc if rc >= 0 else 128 - rc
+
+
+def load_test_backend(path, local_rank):
+    """ESCOIN_BENCH_TEST_BACKEND=<file.py>: tests only (tests/bench_stub_backend.py) -- lets the CPU
+    suite run THIS file's launcher, rendezvous and reporting as one command on a box without a GPU.
+    The bench line of such a run says so (`backend`, `test_backend`) and is not a measurement."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("escoin_bench_test_backend", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.make_backend(local_rank)
+
+
 def main():
     args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # nothing below runs in the launcher
     # the host's CPU share is read BEFORE any OpenMP runtime exists: with OMP_PROC_BIND set, the
     # runtime torch loads pins this thread to one core and the affinity mask then reads "2 threads"
     global _HOST_INFO
@@ -559,15 +644,17 @@ def main():
     pkg = ge.load_package()
     synth = pkg.synth
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`"
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     kernel = {"auto": pkg.KERNEL_AUTO, "generic": pkg.KERNEL_GENERIC, "tiled": pkg.KERNEL_TILED}[args.kernel]
-    be = HipBackend(pkg, local_rank, kernel)
+    test_backend = os.environ.get("ESCOIN_BENCH_TEST_BACKEND")
+    if test_backend:
+        be = load_test_backend(test_backend, local_rank)
+        args.dist_backend = be.dist_backend
+    else:
+        be = HipBackend(pkg, local_rank, kernel)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -576,9 +663,16 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     out = run(args, be, pkg, synth, ge.load_oracle, dist if world > 1 else None)
     if out is not None:
+        if test_backend:
+            out["test_backend"] = True
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    # wrong results are not a throughput: the line above carries "parity_failed", the exit code says it too
+    failed = bool(out.get("parity_failed")) if out is not None else False
+    if failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -155,7 +155,12 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = wave + 4 * q;          // rows k0 + 2 i, k0 + 2 i + 1
-        dma16(rB, ldsB + (unsigned)(buf * kBK * kBN * 4 + i * 1024), fb_pix[0], (unsigned)((size_t)(k0 + 2 * i) * hw * 4));
+        // rows past K (the last k-step when Cg % 32 != 0) are channels of the next conv group, of the
+        // next image or memory past the blob: A's zero padding does not make them harmless (0 * Inf,
+        // 0 * NaN = NaN), so they are staged as zeros like the gathered path's 0x7FFF taps -- the
+        // range check sees the VGPR offset only, hence the marker goes there
+        const unsigned vo = (k0 + 2 * i + (lane >> 5) < a.K) ? fb_pix[0] : kOOB;
+        dma16(rB, ldsB + (unsigned)(buf * kBK * kBN * 4 + i * 1024), vo, (unsigned)((size_t)(k0 + 2 * i) * hw * 4));
       }
     } else {
       // this wave's 8 rows of the k-step: their taps are 64 contiguous bytes at a wave-uniform address

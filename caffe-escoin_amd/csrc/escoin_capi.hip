@@ -263,8 +263,16 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
                                            (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_GEMM);
     p->conv_mode = value;
     // to or from LOWERED_GEMM on an aligned plan: the dense / sparse device structures are rebuilt
-    // from the CSR the plan holds (the other three modes share theirs)
-    if (regroup) return upload(p, nullptr);
+    // from the CSR the plan holds (the other three modes share theirs).  The plan is not aligned
+    // while that happens: if an allocation fails, the next forward reports ESCOIN_ESTATE instead of
+    // launching on freed pointers.  The rebuild must happen on the device the plan lives on.
+    if (regroup) {
+      int dev = -1;
+      if (hipGetDevice(&dev) != hipSuccess || dev != p->device)
+        return fail(ESCOIN_ESTATE, "conv_mode flip on an aligned plan: the current device is not the plan's device");
+      p->aligned = false;
+      return upload(p, nullptr);
+    }
   } else if (!strcmp(key, "dense_gate")) {
     p->dense_gate = value != 0;
   } else {
@@ -330,6 +338,13 @@ int escoin_plan_set_csr(escoin_plan *p, const int *rowptr, const int *colidx, co
     for (int j = 0; j < n_g; ++j)
       if (colidx[base + j] < 0 || colidx[base + j] >= g.kdim)
         return fail(ESCOIN_EINVAL, "set_csr: column index out of range");
+    // caffe_cpu_sparse_dense2csr scans a row left to right (math_functions.cpp:92-105): columns are
+    // strictly ascending within a row.  The stream builder's row grouping and the reference-order
+    // kernels (bit-exact summation order) rely on it, so anything else is refused, not repaired.
+    for (int m = 0; m < g.Mg; ++m)
+      for (int j = rp[m] + 1; j < rp[m + 1]; ++j)
+        if (colidx[base + j] <= colidx[base + j - 1])
+          return fail(ESCOIN_EINVAL, "set_csr: column indices must be strictly ascending within a row");
     p->rowptr[grp].assign(rp, rp + g.Mg + 1);
     p->colidx[grp].assign(colidx + base, colidx + base + n_g);
     p->values[grp].assign(values + base, values + base + n_g);
@@ -386,6 +401,11 @@ int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_de
   if (n_images < 0 || n_images > p->g.d.N)
     return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
   if (n_images == 0) return ESCOIN_OK;
+  {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != p->device)
+      return fail(ESCOIN_ESTATE, "forward: the current device is not the device the plan was aligned on");
+  }
   hipStream_t s = (hipStream_t)stream;
   // LOWERED_SPARSE lowers every group, whatever AUTO decided for the direct path
   if (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && p->kernel_choice != ESCOIN_KERNEL_DENSE)

@@ -8,10 +8,10 @@ import socket
 import sys
 import time
 
-import numpy as np
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _free_port():
@@ -22,78 +22,7 @@ def _free_port():
     return p
 
 
-class _Event(object):
-    def __init__(self):
-        self.t = 0.0
-
-    def record(self):
-        self.t = time.perf_counter()
-
-    def elapsed_time(self, other):
-        return max(1e-6, (other.t - self.t) * 1e3)
-
-
-class _StubPlan(object):
-    """Same surface as caffe_escoin_amd.Plan; arithmetic by the oracle (test stub)."""
-    kernel_name = "oracle_stub"
-
-    def __init__(self, oracle, torch, s):
-        self.o, self.torch, self.s = oracle, torch, s
-        self.w = None
-
-    def weight_align(self, w):
-        self.w = np.ascontiguousarray(w, np.float32)
-
-    def get_csr(self):
-        s = self.s
-        mg, cg = s.M // s.group, s.C // s.group
-        rps, cis, vas, ngs = [], [], [], []
-        for g in range(s.group):
-            rp, ci, va = self.o.dense2csr(self.w[g * mg:(g + 1) * mg].reshape(mg, cg * s.KH * s.KW))
-            rps.append(rp); cis.append(ci); vas.append(va); ngs.append(len(ci))
-        return np.concatenate(rps), np.concatenate(cis), np.concatenate(vas), np.array(ngs, np.int32)
-
-    def set_csr(self, rp, ci, va, ng):
-        s = self.s
-        mg, cg = s.M // s.group, s.C // s.group
-        w = np.zeros((s.M, cg * s.KH * s.KW), np.float32)
-        off = 0
-        for g in range(s.group):
-            r = rp[g * (mg + 1):(g + 1) * (mg + 1)]
-            for m in range(mg):
-                w[g * mg + m, ci[off + r[m]:off + r[m + 1]]] = va[off + r[m]:off + r[m + 1]]
-            off += int(ng[g])
-        self.w = w.reshape(s.M, cg, s.KH, s.KW)
-
-    def forward(self, x, bias=None, top=None):
-        s = self.s
-        g = self.o.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
-                        s.dil_h, s.dil_w, s.group)
-        y = self.o.conv_forward(g, x.numpy(), self.w, None if bias is None else bias.numpy(), gate=False)
-        y = self.torch.from_numpy(y)
-        if top is not None:
-            top.copy_(y)
-            return top
-        return y
-
-
-class _StubBackend(object):
-    name = "stub"
-    dist_backend = "gloo"
-
-    def __init__(self, oracle):
-        import torch
-        self.torch, self.oracle = torch, oracle
-        self.device = torch.device("cpu")
-
-    def make_plan(self, shape):
-        return _StubPlan(self.oracle, self.torch, shape)
-
-    def synchronize(self):
-        pass
-
-    def event(self):
-        return _Event()
+from bench_stub_backend import StubBackend as _StubBackend  # noqa: E402
 
 
 def _worker(rank, world, port, out_dir, argv):

@@ -1,0 +1,91 @@
+"""`python bench.py --gpus N` as ONE command: the parent starts its own ranks (child processes of
+torch.distributed.run), never touches the GPU, relays rank 0's JSON line and the worst exit code --
+the counterpart of the reference's single `caffe` command starting a worker per GPU
+(tools/caffe.cpp:254-256, parallel.cpp:328-358).  Runs here on two gloo ranks with the test backend
+(tests/bench_stub_backend.py: forward by the oracle)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "bench_stub_backend.py")
+
+
+def _run_one_command(extra, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env["ESCOIN_BENCH_TEST_BACKEND"] = STUB
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    return p.returncode, lines, p.stderr.decode()
+
+
+def test_one_command_starts_two_ranks_and_prints_one_json_line():
+    rc, lines, err = _run_one_command(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "lenet",
+                                       "--batch", "3", "--no-cpu"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines                 # ONE line on stdout, everything else on stderr
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 6
+    assert out["weight_broadcast_ms"] is not None and out["weight_broadcast_ms"] >= 0
+    assert out["dist_backend"] == "gloo" and out["test_backend"] is True
+    assert out["parity_max_rel_err"] <= 1e-4 and out["cross_rank_checksum_rel_diff"] <= 1e-5
+    assert "torch.distributed.run" in err         # the launcher said what it started
+
+
+def test_one_command_strong_scaling_global_batch():
+    rc, lines, err = _run_one_command(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "lenet",
+                                       "--global-batch", "5", "--no-cpu"])
+    assert rc == 0, err[-2000:]
+    out = json.loads(lines[-1])
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 5 and out["n_ranks_seen"] == 2
+
+
+def test_launcher_relays_a_failing_rank():
+    """A rank that dies (here: a workload name no rank accepts) must not look like a success."""
+    rc, lines, err = _run_one_command(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "nope",
+                                       "--no-cpu"])
+    assert rc != 0
+    assert not lines
+
+
+def test_launcher_does_not_import_torch_or_touch_the_gpu():
+    """The parent of `--gpus N` must start its children before anything initialises HIP: the
+    launcher path imports neither torch nor the package's library."""
+    code = (
+        "import sys, os\n"
+        "sys.argv = ['bench.py', '--gpus', '2']\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench, subprocess\n"
+        "class P(object):\n"
+        "    stdout = []\n"
+        "    def wait(self): return 7\n"
+        "seen = {}\n"
+        "def popen(cmd, **kw):\n"
+        "    seen['cmd'] = cmd\n"
+        "    seen['torch'] = 'torch' in sys.modules\n"
+        "    seen['pkg'] = 'caffe_escoin_amd' in sys.modules\n"
+        "    return P()\n"
+        "subprocess.Popen = popen\n"
+        "os.environ.pop('WORLD_SIZE', None)\n"
+        "try:\n"
+        "    bench.main()\n"
+        "except SystemExit as e:\n"
+        "    rc = e.code\n"
+        "assert rc == 7, rc\n"
+        "assert seen['torch'] is False and seen['pkg'] is False, seen\n"
+        "assert 'torch' not in sys.modules\n"
+        "c = seen['cmd']\n"
+        "assert c[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in c and '2' in c\n"
+        "assert c[-2:] == ['--gpus', '2']\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=120)
+    assert p.returncode == 0 and b"ok" in p.stdout, p.stderr.decode()[-2000:]

@@ -117,6 +117,12 @@ def test_set_csr_validates_on_host(pkg):
         plan.set_csr(rp, ci, va, [2])
     with pytest.raises(pkg.EscoinError):
         plan.set_csr(np.array([0, 1, 2], np.int32), np.array([0, 99], np.int32), va, [2])
+    # columns within a row: strictly ascending, as caffe_cpu_sparse_dense2csr's scan leaves them
+    # (math_functions.cpp:92-105); unsorted or duplicated columns are refused before any device work
+    for bad in ([5, 0], [5, 5]):
+        with pytest.raises(pkg.EscoinError) as e:
+            plan.set_csr(np.array([0, 2, 2], np.int32), np.array(bad, np.int32), va, [2])
+        assert "ascending" in str(e.value)
 
 
 def test_package_is_importable_under_alias():

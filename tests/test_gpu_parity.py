@@ -586,3 +586,81 @@ sys.exit(0 if err <= 1e-4 else 1)
                          timeout=600)
     assert out.returncode == 0, out.stdout.decode()
     assert "REL_ERR" in out.stdout.decode()
+
+
+def test_dense_pointwise_k_tail_never_reads_its_neighbours(pkg, oracle, synth, torch_cuda):
+    """Dense (fp32 MFMA) kernel on a pointwise layer whose channels per group are NOT a multiple of
+    the 32-wide k-step (GoogLeNet 4e: 528): the last k-step's rows >= K are channels of the next
+    conv group, of the next image, or memory past the blob.  The reference GEMM never reads them
+    (base_conv_layer.cpp:713-746); a zero weight does not make them harmless (0 * NaN = NaN), so
+    the staging must deliver zeros there.  NaNs are planted in all three places."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    # two groups of 40 channels (tail of 24 rows in the second k-step), 8 x 8 = whole quads of pixels
+    s = synth.shape("k_tail", 3, 80, 8, 8, 32, 1, group=2, sparsity=0.3, bias=True)
+    w, b = synth.pruned_weights(s, 91), synth.bias_vector(s, 92)
+    x = synth.activations(s, 93)
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
+                    s.dil_h, s.dil_w, s.group)
+    want = oracle.conv_forward(g, x, w, b, gate=False)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_DENSE)
+    plan.weight_align(w)
+    assert "dense_mfma" in plan.kernel_name
+    bias = torch.from_numpy(b).to(dev)
+    per_img = s.C * s.H * s.W
+    # (1) after the blob: the bottom is a window of a NaN-filled allocation
+    big = torch.full((5 * per_img,), float("nan"), device=dev)
+    big[per_img:4 * per_img] = torch.from_numpy(x).to(dev).reshape(-1)
+    bottom = big[per_img:4 * per_img].view(3, s.C, s.H, s.W)
+    got = plan.forward(bottom, bias).cpu().numpy()
+    assert np.isfinite(got).all(), "rows past K reached memory after the blob"
+    assert rel_err(got, want) <= TOL
+    # (2) the next image: only image 0 is computed, image 1 is all NaN
+    xs = torch.from_numpy(x).to(dev).clone()
+    xs[1:] = float("nan")
+    top = torch.zeros((3, s.M, s.H, s.W), device=dev)
+    plan.forward_ptr(xs.data_ptr(), bias.data_ptr(), top.data_ptr(), 1,
+                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got0 = top[0].cpu().numpy()
+    assert np.isfinite(got0).all(), "rows past K of the last group reached the next image"
+    assert rel_err(got0, want[0]) <= TOL
+    # (3) the next conv group: group 1's channels are NaN, group 0's outputs must not notice
+    xg = torch.from_numpy(x).to(dev).clone()
+    xg[:, s.C // 2:] = float("nan")
+    gotg = plan.forward(xg, bias).cpu().numpy()[:, :s.M // 2]
+    assert np.isfinite(gotg).all(), "rows past K of group 0 reached group 1's channels"
+    assert rel_err(gotg, want[:, :s.M // 2]) <= TOL
+    plan.close()
+
+
+def test_global_batch_2048_on_one_gpu(pkg, oracle, synth, torch_cuda):
+    """BASELINE.json configs[3] at its strong-scaling N = 1 point: the whole batch of 2048 on ONE
+    GPU, real size (res3 shape: 822 MB bottom, 822 MB top; res2 shape: 1.6 GB each, with the tiling
+    chosen for N = 2048).  Images 0, 1023 and 2047 are checked against the oracle, and the batch
+    independence of the rest through per-image checksums of a repeated image."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    for k, idx in enumerate((1, 0)):
+        s = synth.resnet50_3x3(N=2048)[idx]
+        w = synth.pruned_weights(s, 8100 + k)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+        plan.weight_align(w)
+        err, name = _check_full_batch(pkg, oracle, synth, torch, s, 8100 + k, plan=plan,
+                                      images=(0, 1023, 2047))
+        assert "tiled" in name and err <= TOL, "%s @N=2048 via %s: %g" % (s.name, name, err)
+        # every image through the same arithmetic: a batch made of ONE image repeated 2048 times
+        # must give 2048 identical outputs (bitwise), wherever the image falls in a tile
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(8200 + k)
+        one = torch.rand((1, s.C, s.H, s.W), device=dev, generator=gen) * 2 - 1
+        x = one.expand(s.N, -1, -1, -1).contiguous()
+        top = plan.forward(x)
+        torch.cuda.synchronize()
+        ref = top[0:1]
+        same = (top == ref).all(dim=(1, 2, 3))
+        assert bool(same.all()), "%s: images %s differ from image 0" % (
+            s.name, torch.nonzero(~same).flatten()[:8].tolist())
+        del x, top
+        plan.close()
+    torch.cuda.empty_cache()
