@@ -555,7 +555,8 @@ def parse_args(argv=None):
     ap.add_argument("--global-batch", type=int, default=None,
                     help="total images over all GPUs (strong scaling; BASELINE configs[3]: 2048)")
     ap.add_argument("--sparsity", type=float, default=None)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "tiled"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "tiled", "jit"],
+                    help="auto = generated code (jit) where available; tiled = the LDS-staged stream kernel")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -648,7 +649,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
-    kernel = {"auto": pkg.KERNEL_AUTO, "generic": pkg.KERNEL_GENERIC, "tiled": pkg.KERNEL_TILED}[args.kernel]
+    kernel = {"auto": pkg.KERNEL_AUTO, "generic": pkg.KERNEL_GENERIC, "tiled": pkg.KERNEL_TILED,
+              "jit": pkg.KERNEL_JIT}[args.kernel]
     test_backend = os.environ.get("ESCOIN_BENCH_TEST_BACKEND")
     if test_backend:
         be = load_test_backend(test_backend, local_rank)

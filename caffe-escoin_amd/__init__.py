@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ESCOIN_LIB: A/B experiments against another build of the library
 LIB_PATH = os.environ.get("ESCOIN_LIB") or os.path.join(_HERE, "libescoin_hip.so")
 
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED, KERNEL_DENSE = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED, KERNEL_DENSE, KERNEL_JIT = 0, 1, 2, 3, 4
 CONV_MODE_LOWERED_GEMM, CONV_MODE_LOWERED_SPARSE, CONV_MODE_SCONV, CONV_MODE_SCONV_PAR = 0, 1, 2, 3
 
 # every symbol include/escoin.h declares (tests check the library exports all of them)

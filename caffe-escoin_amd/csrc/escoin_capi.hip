@@ -64,6 +64,7 @@ static void free_device(escoin_plan *p) {
   p->d_unit_hdr = nullptr;
   if (p->d_chan) (void)hipFree(p->d_chan);
   p->d_chan = nullptr;
+  jit_unload(&p->jit_module);
   if (p->d_col) (void)hipFree(p->d_col);
   p->d_col = nullptr;
   p->col_bytes = 0;
@@ -170,13 +171,24 @@ static int upload(escoin_plan *p, hipStream_t stream) {
     p->aligned = true;
     return ESCOIN_OK;
   }
-  const bool want_tiled = p->kernel_choice == ESCOIN_KERNEL_TILED ||
-                          (p->kernel_choice == ESCOIN_KERNEL_AUTO && tiled_supported(g));
+  const bool explicit_tiled = p->kernel_choice == ESCOIN_KERNEL_TILED || p->kernel_choice == ESCOIN_KERNEL_JIT;
+  const bool want_tiled = explicit_tiled || (p->kernel_choice == ESCOIN_KERNEL_AUTO && tiled_supported(g));
   if (want_tiled) {
     if (!tiled_supported(g))
       return fail(ESCOIN_EINVAL, "tiled kernel requested for a geometry it does not support");
-    int rc = tiled_build(p, stream);   // leaves tiled.enabled false when the stream does not fit LDS
-    if (rc != ESCOIN_OK) return rc;
+    // AUTO: generated code where it can be had, else the LDS-staged stream
+    const bool try_jit = p->kernel_choice == ESCOIN_KERNEL_JIT || (p->kernel_choice == ESCOIN_KERNEL_AUTO && jit_available());
+    int rc = ESCOIN_OK;
+    if (try_jit) {
+      rc = tiled_build(p, stream, true);
+      if (rc != ESCOIN_OK && p->kernel_choice == ESCOIN_KERNEL_JIT) return rc;
+      if (!p->tiled.enabled && p->kernel_choice == ESCOIN_KERNEL_JIT)
+        return fail(ESCOIN_EINVAL, "generated-code kernel requested but the layer does not fit it");
+    }
+    if (!p->tiled.enabled) {
+      rc = tiled_build(p, stream, false);   // leaves tiled.enabled false when the stream does not fit LDS
+      if (rc != ESCOIN_OK) return rc;
+    }
     if (!p->tiled.enabled && p->kernel_choice == ESCOIN_KERNEL_TILED)
       return fail(ESCOIN_EINVAL, "tiled kernel requested but its weight stream does not fit the LDS budget");
   }
@@ -253,7 +265,7 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
     return ESCOIN_OK;
   }
   if (!strcmp(key, "kernel")) {
-    if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_DENSE)
+    if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_JIT)
       return fail(ESCOIN_EINVAL, "unknown kernel id");
     p->kernel_choice = value;
   } else if (!strcmp(key, "conv_mode")) {

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "escoin.h"
+#include "jit_module.h"
 #include "stream_builder.h"
 
 namespace escoin {
@@ -53,6 +54,8 @@ struct TiledConfig {
   Tiling tiling;       // the tiling itself (chosen once in WeightAlign; launches only read it)
   int stage_bytes = 0; // LDS bytes of one wave's weight-stream staging area
   int nbuf = 2;        // plane / staging buffers per workgroup
+  bool jit = false;    // the walk is generated code (jit_codegen.h) instead of the LDS-staged stream
+  long jit_rows = 0, jit_records = 0;
 };
 
 }  // namespace escoin
@@ -80,7 +83,8 @@ struct escoin_plan {
   // device arrays for the tiled kernel
   escoin::TiledConfig tiled;
   unsigned *d_stream = nullptr;   // unit bodies of the weight stream (stream_builder.h)
-  unsigned *d_unit_hdr = nullptr; // 8 dwords per (conv group, oc group, ic block)
+  unsigned *d_unit_hdr = nullptr; // 8 dwords per (conv group, oc group, ic block); generated code: 1 (code offset)
+  escoin::JitModule jit_module;   // generated-code kernel: the loaded code object and where its code lives
   unsigned *d_chan = nullptr;     // slot -> output channel (WeightStream::chan)
   size_t stream_words = 0;
 
@@ -111,7 +115,7 @@ const char *generic_kernel_name(bool relu);
 
 // sconv_tiled.hip
 bool tiled_supported(const Geometry &g);
-int tiled_build(escoin_plan *p, hipStream_t stream);  // fills p->tiled, uploads streams
+int tiled_build(escoin_plan *p, hipStream_t stream, bool jit);  // fills p->tiled, uploads streams / loads generated code
 int launch_tiled(const escoin_plan *p, const float *bottom, const float *bias, float *top,
                  int n_images, hipStream_t stream);
 const char *tiled_kernel_name(const escoin_plan *p);

@@ -1,0 +1,100 @@
+// jit_codegen.h -- WeightAlign's code generator: the sparsity pattern compiled into gfx950 code.
+//
+// The weight stream of the LDS-staged kernel (stream_builder.h) is DATA that a generic loop
+// decodes at run time: per input row a meta word through v_readfirstlane, a row offset and up to
+// six accumulator indices extracted with scalar shifts, the accumulator selected through M0
+// (GPR-index mode) -- 13.7 instructions around the 10.4 packed FMAs of an average row at 90 %
+// sparsity, and the walk is bound by instruction issue.  A pruned layer's pattern
+// is fixed once WeightAlign has run (the reference builds its CSR exactly once per weight load,
+// base_conv_layer.cpp:46-273), so here WeightAlign goes one step further and emits the walk of
+// every (conv group, oc-group, input-channel block) unit as STRAIGHT-LINE machine code:
+//
+//   per nonempty input row      ds_read_b128 x2     the lane's tile-A / tile-B quads at an
+//                                                  IMMEDIATE LDS offset (no address arithmetic)
+//                               s_waitcnt lgkmcnt  counted: rows are read two ahead
+//   per nonzero                 s_mov_b32 s, value  the weight as a 32-bit literal
+//                               v_pk_fma_f32 x4     into STATICALLY numbered accumulators
+//   at the end of the unit      s_setpc_b64 s[30:31]
+//
+// = 5 instructions per nonzero + 2.x per row, no meta words, no index mode, no LDS staging of the
+// weights (the nonzero stream reaches the wave through instruction fetch: one cache line of code
+// carries 1.6 nonzeros; every workgroup column runs the same code, so it comes from L2).  The
+// code is megabytes per layer and never repeats inside a tile; tools/probes/gen_probe_istream.py
+// measured that instruction mix at 95-104 packed-FMA TFLOP/s from 8 MiB of straight-line code
+// per workgroup, every wave in its own part, against 52 in the decoded walk.
+//
+// Pure C++ (no HIP): unit-testable on a CPU-only box (tests/cpp/emulate_tiled.cpp interprets the
+// generated code; tests/test_jit_codegen.py checks the encoders against llvm-mc).
+//
+// Register contract with sconv_tiled.hip (the compiled part owns v[0:31]):
+//   v32  LDS byte address of the lane's tile-A quad (plane row 0, channel 0 of the block being
+//        walked), v33 = v32 + 1024 (tile B)
+//   v[36:43], v[44:51], v[52:59]   three sets of input quads (A: +0..3, B: +4..7)
+//   v[64:159] / v[160:255]         tile-A / tile-B accumulators, as in the LDS-staged kernel
+//   s40 / s42 (pairs s[40:41], s[42:43])   weights, alternating
+//   s[30:31] return address (the unit is entered with s_swappc_b64)
+#ifndef ESCOIN_JIT_CODEGEN_H_
+#define ESCOIN_JIT_CODEGEN_H_
+
+#include <cstdint>
+#include <vector>
+
+#include "stream_builder.h"
+
+namespace escoin {
+namespace jit {
+
+constexpr int kVAddrA = 32, kVAddrB = 33;
+constexpr int kVIn0 = 36;          // input sets at 36, 44, 52
+constexpr int kInSets = 3;
+constexpr int kAccA = 64, kAccB = 160;
+constexpr int kSWeight0 = 40, kSWeight1 = 42;
+constexpr int kUnitAlign = 64;     // bytes: a unit starts on an instruction-cache line
+
+// ---- instruction encoders (gfx950; checked against llvm-mc in tests/test_jit_codegen.py) ----
+// ds_read_b128 v[vdst:vdst+3], v<vaddr> offset:<off>
+inline void enc_ds_read_b128(std::vector<uint32_t> &c, int vdst, int vaddr, unsigned off) {
+  c.push_back(0xD9FE0000u | (off & 0xFFFFu));
+  c.push_back(((uint32_t)vdst << 24) | (uint32_t)vaddr);
+}
+// s_waitcnt lgkmcnt(n)   (vmcnt, expcnt not waited for)
+inline void enc_waitcnt_lgkm(std::vector<uint32_t> &c, int n) { c.push_back(0xBF8CC07Fu | ((uint32_t)(n & 15) << 8)); }
+// s_mov_b32 s<sdst>, <32-bit literal>
+inline void enc_s_mov_lit(std::vector<uint32_t> &c, int sdst, uint32_t lit) {
+  c.push_back(0xBE8000FFu | ((uint32_t)sdst << 16));
+  c.push_back(lit);
+}
+// v_pk_fma_f32 v[acc:acc+1], s[sw:sw+1], v[x:x+1], v[acc:acc+1] op_sel_hi:[0,1,1]
+// (both halves multiply by the LOW dword of the SGPR pair: one weight, two pixels)
+inline void enc_pk_fma(std::vector<uint32_t> &c, int acc, int sw, int x) {
+  c.push_back(0xD3B04000u | (uint32_t)acc);
+  c.push_back((uint32_t)sw | ((256u + (uint32_t)x) << 9) | ((256u + (uint32_t)acc) << 18) | (2u << 27));
+}
+inline void enc_setpc_return(std::vector<uint32_t> &c) { c.push_back(0xBE801D1Eu); }   // s_setpc_b64 s[30:31]
+inline void enc_setprio(std::vector<uint32_t> &c, int p) { c.push_back(0xBF8F0000u | (uint32_t)(p & 3)); }
+inline void enc_nop(std::vector<uint32_t> &c) { c.push_back(0xBF800000u); }
+
+struct Options {
+  int depth = 2;          // rows read ahead (1 or 2; three input sets allow 2)
+  int hoist_weight = 1;   // s_mov of record j+1 issued before the FMAs of record j
+  int prio_rows = 0;      // > 0: s_setprio alternates every this many rows (0: never)
+  int ablate = 0;         // timing experiments only (ESCOIN_JIT_ABL; wrong results): 1 no FMAs, 2 no LDS
+                          // reads, 4 no weight moves, 8 empty units
+};
+Options options_from_env();
+
+struct Program {
+  std::vector<uint32_t> code;       // every unit, back to back, each aligned to kUnitAlign bytes
+  std::vector<uint32_t> unit_off;   // [conv group][n_ocg][n_icb]: byte offset of the unit's entry
+  std::vector<uint32_t> chan;       // slot -> output channel, as WeightStream::chan
+  long n_rows = 0, n_records = 0;
+  bool overflow = false;            // an LDS offset does not fit the instruction's 16-bit field
+};
+
+Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,
+                      const std::vector<std::vector<int>> &colidx,
+                      const std::vector<std::vector<float>> &values, const Options &opt);
+
+}  // namespace jit
+}  // namespace escoin
+#endif

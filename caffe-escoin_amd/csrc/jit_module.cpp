@@ -1,0 +1,209 @@
+// jit_module.cpp -- see jit_module.h
+#include "jit_module.h"
+
+#include <amd_comgr/amd_comgr.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "escoin_plan.h"
+
+namespace escoin {
+
+namespace {
+
+// The wrapper: a locator kernel (stores the address of escoin_jit_code through its one pointer
+// argument) and the generated code behind it, in the executable segment of a code object the HIP
+// runtime loads like any other.  Directives as hipcc emits them for gfx950 (code object v6).
+const char *kWrapper = R"(
+	.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+	.amdhsa_code_object_version 6
+	.text
+	.protected	escoin_jit_locator
+	.globl	escoin_jit_locator
+	.p2align	8
+	.type	escoin_jit_locator,@function
+escoin_jit_locator:
+	s_load_dwordx2 s[0:1], s[0:1], 0x0
+	s_getpc_b64 s[2:3]
+.Lpc:
+	s_add_u32 s2, s2, escoin_jit_code-.Lpc
+	s_addc_u32 s3, s3, 0
+	v_mov_b32_e32 v2, 0
+	v_mov_b32_e32 v0, s2
+	v_mov_b32_e32 v1, s3
+	s_waitcnt lgkmcnt(0)
+	global_store_dwordx2 v2, v[0:1], s[0:1]
+	s_endpgm
+.Lfunc_end0:
+	.size	escoin_jit_locator, .Lfunc_end0-escoin_jit_locator
+	.p2align	8
+	.globl	escoin_jit_code
+escoin_jit_code:
+	.incbin "%BLOB%"
+	.fill 64, 4, 0xBF800000
+	.section	.rodata,"a",@progbits
+	.p2align	6, 0x0
+	.amdhsa_kernel escoin_jit_locator
+		.amdhsa_group_segment_fixed_size 0
+		.amdhsa_private_segment_fixed_size 0
+		.amdhsa_kernarg_size 8
+		.amdhsa_user_sgpr_count 2
+		.amdhsa_user_sgpr_kernarg_segment_ptr 1
+		.amdhsa_system_sgpr_workgroup_id_x 1
+		.amdhsa_system_vgpr_workitem_id 0
+		.amdhsa_next_free_vgpr 3
+		.amdhsa_next_free_sgpr 4
+		.amdhsa_accum_offset 4
+		.amdhsa_reserve_vcc 0
+		.amdhsa_float_denorm_mode_32 3
+		.amdhsa_float_denorm_mode_16_64 3
+		.amdhsa_dx10_clamp 1
+		.amdhsa_ieee_mode 1
+	.end_amdhsa_kernel
+	.amdgpu_metadata
+---
+amdhsa.kernels:
+  - .agpr_count:     0
+    .args:
+      - .address_space:  global
+        .offset:         0
+        .size:           8
+        .value_kind:     global_buffer
+    .group_segment_fixed_size: 0
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: 8
+    .max_flat_workgroup_size: 1024
+    .name:           escoin_jit_locator
+    .private_segment_fixed_size: 0
+    .sgpr_count:     8
+    .sgpr_spill_count: 0
+    .symbol:         escoin_jit_locator.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     3
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+	.end_amdgpu_metadata
+)";
+
+std::string comgr_error(amd_comgr_status_t s, const char *what) {
+  const char *m = "?";
+  (void)amd_comgr_status_string(s, &m);
+  return std::string(what) + ": " + m;
+}
+
+#define ESCOIN_CG_TRY(expr)                                                             \
+  do {                                                                                  \
+    amd_comgr_status_t s__ = (expr);                                                    \
+    if (s__ != AMD_COMGR_STATUS_SUCCESS) { err = comgr_error(s__, #expr); goto done; }  \
+  } while (0)
+
+// source text -> executable code object (ELF bytes); "" on success, else the error
+std::string assemble_and_link(const std::string &src, std::vector<char> *elf) {
+  std::string err;
+  amd_comgr_data_t d{}, out{};
+  amd_comgr_data_set_t in{}, rel{}, exe{};
+  amd_comgr_action_info_t info{};
+  bool have_d = false, have_in = false, have_rel = false, have_exe = false, have_info = false, have_out = false;
+  size_t sz = 0;
+  ESCOIN_CG_TRY(amd_comgr_create_data(AMD_COMGR_DATA_KIND_SOURCE, &d));
+  have_d = true;
+  ESCOIN_CG_TRY(amd_comgr_set_data(d, src.size(), src.data()));
+  ESCOIN_CG_TRY(amd_comgr_set_data_name(d, "escoin_jit.s"));
+  ESCOIN_CG_TRY(amd_comgr_create_data_set(&in));
+  have_in = true;
+  ESCOIN_CG_TRY(amd_comgr_create_data_set(&rel));
+  have_rel = true;
+  ESCOIN_CG_TRY(amd_comgr_create_data_set(&exe));
+  have_exe = true;
+  ESCOIN_CG_TRY(amd_comgr_data_set_add(in, d));
+  ESCOIN_CG_TRY(amd_comgr_create_action_info(&info));
+  have_info = true;
+  ESCOIN_CG_TRY(amd_comgr_action_info_set_isa_name(info, "amdgcn-amd-amdhsa--gfx950"));
+  ESCOIN_CG_TRY(amd_comgr_do_action(AMD_COMGR_ACTION_ASSEMBLE_SOURCE_TO_RELOCATABLE, info, in, rel));
+  ESCOIN_CG_TRY(amd_comgr_do_action(AMD_COMGR_ACTION_LINK_RELOCATABLE_TO_EXECUTABLE, info, rel, exe));
+  ESCOIN_CG_TRY(amd_comgr_action_data_get_data(exe, AMD_COMGR_DATA_KIND_EXECUTABLE, 0, &out));
+  have_out = true;
+  ESCOIN_CG_TRY(amd_comgr_get_data(out, &sz, nullptr));
+  elf->resize(sz);
+  ESCOIN_CG_TRY(amd_comgr_get_data(out, &sz, elf->data()));
+done:
+  if (have_out) (void)amd_comgr_release_data(out);
+  if (have_d) (void)amd_comgr_release_data(d);
+  if (have_in) (void)amd_comgr_destroy_data_set(in);
+  if (have_rel) (void)amd_comgr_destroy_data_set(rel);
+  if (have_exe) (void)amd_comgr_destroy_data_set(exe);
+  if (have_info) (void)amd_comgr_destroy_action_info(info);
+  return err;
+}
+
+}  // namespace
+
+bool jit_available() {
+  static const bool on = !(getenv("ESCOIN_JIT") && atoi(getenv("ESCOIN_JIT")) == 0);
+  return on;
+}
+
+int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream) {
+  if (code.empty()) return fail(ESCOIN_EINVAL, "jit: empty program");
+  // the bytes reach the assembler through .incbin: a file, gone again before this returns
+  const char *tmpdir = getenv("TMPDIR");
+  std::string path = std::string(tmpdir && *tmpdir ? tmpdir : "/tmp") + "/escoin_jit_XXXXXX";
+  std::vector<char> pbuf(path.begin(), path.end());
+  pbuf.push_back(0);
+  const int fd = mkstemp(pbuf.data());
+  if (fd < 0) return fail(ESCOIN_ENOMEM, "jit: cannot create a temporary file in " + path);
+  const size_t bytes = code.size() * 4;
+  size_t done = 0;
+  while (done < bytes) {
+    const ssize_t n = write(fd, reinterpret_cast<const char *>(code.data()) + done, bytes - done);
+    if (n <= 0) break;
+    done += (size_t)n;
+  }
+  close(fd);
+  std::string src = kWrapper;
+  src.replace(src.find("%BLOB%"), 6, pbuf.data());
+  std::vector<char> elf;
+  const std::string err = done == bytes ? assemble_and_link(src, &elf) : std::string("short write to the temporary file");
+  unlink(pbuf.data());
+  if (!err.empty()) return fail(ESCOIN_EHIP, "jit: " + err);
+  JitModule m;
+  ESCOIN_HIP_TRY(hipModuleLoadData(&m.module, elf.data()));
+  hipFunction_t locator = nullptr;
+  unsigned long long *d_addr = nullptr;
+  hipError_t e = hipModuleGetFunction(&locator, m.module, "escoin_jit_locator");
+  if (e == hipSuccess) e = hipMalloc(&d_addr, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemsetAsync(d_addr, 0, sizeof(unsigned long long), stream);
+  if (e == hipSuccess) {
+    void *args[] = {&d_addr};
+    e = hipModuleLaunchKernel(locator, 1, 1, 1, 1, 1, 1, 0, stream, args, nullptr);
+  }
+  unsigned long long addr = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&addr, d_addr, sizeof(addr), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (d_addr) (void)hipFree(d_addr);
+  if (e != hipSuccess || addr == 0) {
+    (void)hipModuleUnload(m.module);
+    return fail(ESCOIN_EHIP, std::string("jit: locating the generated code failed: ") + hipGetErrorString(e));
+  }
+  m.code_base = addr;
+  m.code_bytes = bytes;
+  *out = m;
+  return ESCOIN_OK;
+}
+
+void jit_unload(JitModule *m) {
+  if (m && m->module) (void)hipModuleUnload(m->module);
+  if (m) *m = JitModule();
+}
+
+}  // namespace escoin

@@ -224,14 +224,14 @@ struct Group {
 }  // namespace
 
 std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const std::vector<int> &rowptr,
-                                       const std::vector<int> &colidx) {
+                                       const std::vector<int> &colidx, double group_cost, double record_cost) {
   const int G = t.G, n_ocg = t.n_ocg, Mg = g.Mg;
   std::vector<uint32_t> slot(static_cast<size_t>(n_ocg) * G);
   for (int o = 0; o < n_ocg; ++o)
     for (int gl = 0; gl < G; ++gl) slot[(size_t)o * G + gl] = (uint32_t)std::min(o * G + gl, Mg - 1);
   static const bool enabled = !(getenv("ESCOIN_BALANCE") && atoi(getenv("ESCOIN_BALANCE")) == 0);
   if (!enabled || g.KW == 1 || t.oc_waves < 2 || Mg < 2 * G) return slot;
-  constexpr double kGroupCost = 12.3, kRecordCost = 5.75;
+  const double kGroupCost = group_cost, kRecordCost = record_cost;
   const int rows_per_blk = t.icb * g.KH;
   const int words = (rows_per_blk + 63) / 64;
   const int nb = t.n_icb;

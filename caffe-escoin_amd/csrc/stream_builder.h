@@ -117,8 +117,11 @@ struct WeightStream {
 // Cost of a wave in a block = kGroupCost * nonempty input rows + kRecordCost * nonzeros (the
 // instruction counts of the stream loop).  Greedy pairwise swaps between waves of the same
 // workgroup column, deterministic.  Returns slot -> channel for the group (n_ocg * G entries).
+// (group_cost / record_cost: instructions per nonempty input row / per nonzero of the walk that will
+// run the deal -- 12.3 / 5.75 for the LDS-staged stream loop, 2.5 / 5 for generated code.)
 std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const std::vector<int> &rowptr,
-                                       const std::vector<int> &colidx);
+                                       const std::vector<int> &colidx, double group_cost = 12.3,
+                                       double record_cost = 5.75);
 
 WeightStream build_stream(const ConvGeom &g, const Tiling &t,
                             const std::vector<std::vector<int>> &rowptr,

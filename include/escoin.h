@@ -64,6 +64,9 @@ extern "C" {
 #define ESCOIN_KERNEL_GENERIC 1 /* one lane = one output pixel, CSR order kept    */
 #define ESCOIN_KERNEL_TILED 2   /* LDS-staged tiles, row-grouped weight stream    */
 #define ESCOIN_KERNEL_DENSE 3   /* implicit-GEMM on the fp32 matrix cores (MFMA)  */
+#define ESCOIN_KERNEL_JIT 4     /* LDS-staged tiles; the weight walk is machine code
+                                   WeightAlign generated from the sparsity pattern
+                                   (what AUTO picks for stride-1 layers)            */
 
 /* Geometry of one ConvolutionLayer: what LayerSetUp/Reshape derive from
  * ConvolutionParameter + the bottom shape (base_conv_layer.cpp:276-530). */

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <vector>
 
+#include "jit_codegen.h"
 #include "stream_builder.h"
 
 using namespace escoin;
@@ -25,7 +26,92 @@ static float frand() {
 
 struct Case { int N, C, H, W, M, KH, KW, ph, pw, group; float sparsity; int waves; int lds; int ncu = 1; bool flat = false; };
 
-static int run(const Case &cs) {
+// ---- interpreter of the code jit_codegen.cpp generates (the five instruction forms it emits) ----
+// Registers of one wave: v[lane][256].  LDS reads land only when a counted s_waitcnt retires them
+// (in order), and an FMA whose input register still has a read pending is an error: a wrong wait
+// count in the generator shows up here, not only on the GPU.
+struct JitWave {
+  std::vector<float> v;   // [64][256]
+  JitWave() : v(64 * 256, 0.f) {}
+};
+struct PendingRead { int vdst; std::vector<float> data; };   // data: [64][4]
+
+static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w, const std::vector<float> &lds,
+                        const std::vector<uint32_t> &laneA /* LDS byte address of the lane's tile-A quad */) {
+  std::vector<PendingRead> pending;
+  uint32_t sreg[128] = {0};
+  auto retire_to = [&](size_t keep) {
+    while (pending.size() > keep) {
+      const PendingRead &r = pending.front();
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 4; ++e) w.v[(size_t)lane * 256 + r.vdst + e] = r.data[lane * 4 + e];
+      pending.erase(pending.begin());
+    }
+  };
+  auto is_pending = [&](int reg) {
+    for (const PendingRead &r : pending)
+      if (reg >= r.vdst && reg < r.vdst + 4) return true;
+    return false;
+  };
+  for (long steps = 0; steps < 100000000; ++steps) {
+    if (pc / 4 >= code.size()) { printf("jit: ran off the end of the code\n"); return 3; }
+    const uint32_t d0 = code[pc / 4];
+    if (d0 == 0xBE801D1Eu) {   // s_setpc_b64 s[30:31]
+      if (!pending.empty()) { printf("jit: unit returns with LDS reads pending\n"); return 3; }
+      return 0;
+    }
+    if ((d0 & 0xFFFF0000u) == 0xBF8C0000u) {   // s_waitcnt
+      if ((d0 & 0xF0FFu) != 0xC07Fu) { printf("jit: unexpected s_waitcnt fields\n"); return 3; }
+      retire_to((d0 >> 8) & 15);
+      pc += 4;
+      continue;
+    }
+    if ((d0 & 0xFFFF0000u) == 0xBF8F0000u || d0 == 0xBF800000u) { pc += 4; continue; }   // s_setprio, s_nop
+    const uint32_t d1 = code[pc / 4 + 1];
+    if ((d0 & 0xFFFF0000u) == 0xD9FE0000u) {   // ds_read_b128
+      const unsigned off = d0 & 0xFFFFu;
+      const int vdst = (int)(d1 >> 24), vaddr = (int)(d1 & 0xFF);
+      if ((d1 & 0x00FFFF00u) != 0 || (vaddr != 32 && vaddr != 33) || vdst < 36 || vdst + 3 > 59) { printf("jit: bad ds_read operands\n"); return 3; }
+      if (is_pending(vdst)) { printf("jit: read into a register with a read pending\n"); return 3; }
+      PendingRead r;
+      r.vdst = vdst;
+      r.data.resize(64 * 4);
+      for (int lane = 0; lane < 64; ++lane) {
+        const size_t a = ((size_t)laneA[lane] + (vaddr == 33 ? 1024u : 0u) + off) / 4;
+        for (int e = 0; e < 4; ++e) r.data[lane * 4 + e] = (a + e < lds.size()) ? lds[a + e] : 0.f;
+      }
+      pending.push_back(r);
+      if (pending.size() > 15) { printf("jit: more than 15 LDS reads in flight\n"); return 3; }
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFF80FFFFu) == 0xBE8000FFu) {   // s_mov_b32 s, literal
+      sreg[(d0 >> 16) & 0x7F] = d1;
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFFFFFF00u) == 0xD3B04000u) {   // v_pk_fma_f32 acc, s[w:w+1], v[x:x+1], acc op_sel_hi:[0,1,1]
+      const int acc = (int)(d0 & 0xFF), sw = (int)(d1 & 0x1FF);
+      const int x = (int)((d1 >> 9) & 0x1FF) - 256, acc2 = (int)((d1 >> 18) & 0x1FF) - 256;
+      if (acc != acc2 || acc < 64 || acc > 254 || (acc & 1) || x < 36 || x > 58 || sw > 101 || (d1 >> 27) != 2u) { printf("jit: bad v_pk_fma_f32 operands\n"); return 3; }
+      if (is_pending(x) || is_pending(x + 1)) { printf("jit: FMA reads v%d before its LDS read was waited for\n", x); return 3; }
+      float wv;
+      std::memcpy(&wv, &sreg[sw], 4);
+      for (int lane = 0; lane < 64; ++lane) {
+        float *V = &w.v[(size_t)lane * 256];
+        V[acc] = std::fmaf(wv, V[x], V[acc]);
+        V[acc + 1] = std::fmaf(wv, V[x + 1], V[acc + 1]);
+      }
+      pc += 8;
+      continue;
+    }
+    printf("jit: unknown instruction %08x at %zu\n", d0, pc);
+    return 3;
+  }
+  return 3;
+}
+
+static int run(const Case &cs, bool use_jit) {
   ConvGeom g{cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, 0, 0, 0, 0};
   g.OH = cs.H + 2 * cs.ph - cs.KH + 1;
   g.OW = cs.W + 2 * cs.pw - cs.KW + 1;
@@ -54,6 +140,17 @@ static int run(const Case &cs) {
     }
   }
   WeightStream ws2 = build_stream(g, t, rp, ci, va);
+  jit::Program jp;
+  if (use_jit) {
+    jit::Options jo;
+    jo.depth = 1 + (cs.N & 1);            // both read-ahead depths and both weight placements get exercised
+    jo.hoist_weight = (cs.C >> 1) & 1;
+    jo.prio_rows = (cs.M & 1) ? 2 : 0;
+    jp = jit::build_program(g, t, rp, ci, va, jo);
+    if (jp.overflow) { printf("jit: LDS offset overflow\n"); return 3; }
+    if (jp.n_records != ws2.n_records) { printf("jit: %ld records, stream has %ld\n", jp.n_records, ws2.n_records); return 3; }
+    ws2.chan = jp.chan;                   // (the generated code deals the channels on its own cost model)
+  }
   // the slot -> channel table deals every channel of a conv group exactly once
   if (ws2.chan.size() != (size_t)g.group * t.n_ocg * t.G) { printf("chan table has the wrong size\n"); return 3; }
   for (int cgi = 0; cgi < g.group; ++cgi) {
@@ -66,7 +163,7 @@ static int run(const Case &cs) {
     for (int m = 0; m < g.Mg; ++m)
       if (seen[m] != 1) { printf("channel %d dealt %d times\n", m, seen[m]); return 3; }
   }
-  if (stage_bytes_for(ws2.max_body_bytes) > 16384) { printf("staging area too large\n"); return 5; }
+  if (!use_jit && stage_bytes_for(ws2.max_body_bytes) > 16384) { printf("staging area too large\n"); return 5; }
 
   // reference dense conv (double)
   std::vector<double> want((size_t)g.N * g.M * g.OH * g.OW, 0.0);
@@ -134,7 +231,23 @@ static int run(const Case &cs) {
             const int pw = wave % t.pix_waves, ow_ = wave / t.pix_waves;
             const int ocg = ocblk * t.oc_waves + ow_;
             if (ocg >= t.n_ocg) continue;
-            {
+            if (use_jit) {
+              // registers: the accumulators live in acc[] between blocks (192 per lane, tile A then B)
+              JitWave jw;
+              std::vector<uint32_t> laneA(64);
+              for (int lane = 0; lane < 64; ++lane) {
+                const int fr = (pw * 2) * t.rows_per_slab + lane / t.S4;
+                laneA[lane] = (uint32_t)(((size_t)fr * t.RS + 4 * (lane % t.S4)) * 4);
+                if (t.rows_per_slab * t.RS * 4 != 1024) { printf("tile B is not tile A + 1 KiB\n"); return 3; }
+                for (int r = 0; r < kAccAll; ++r) jw.v[(size_t)lane * 256 + 64 + r] = acc[((size_t)wave * 64 + lane) * kAccAll + r];
+              }
+              const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
+              if (jp.unit_off[ui] % jit::kUnitAlign) { printf("jit: unit not aligned\n"); return 3; }
+              const int rc = jit_run_unit(jp.code, jp.unit_off[ui], jw, lds, laneA);
+              if (rc) return rc;
+              for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < kAccAll; ++r) acc[((size_t)wave * 64 + lane) * kAccAll + r] = jw.v[(size_t)lane * 256 + 64 + r];
+            } else {
               // the unit's body sits in the wave's staging area; row offset and first
               // accumulator of a group come from the previous group's meta word
               const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
@@ -244,9 +357,9 @@ static int run(const Case &cs) {
     maxref = std::fmax(maxref, std::fabs(want[i]));
   }
   const double rel = maxerr / std::fmax(1e-6, maxref);
-  printf("N%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
+  printf("%sN%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
          "groups=%ld recs=%ld recs/group=%.2f rel_err=%.2e\n",
-         cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.S4, t.G,
+         use_jit ? "jit " : "", cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.S4, t.G,
          t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes,
          ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, rel);
   return rel <= 1e-5 ? 0 : 1;
@@ -284,7 +397,10 @@ int main() {
       {3, 6, 4, 4, 12, 1, 1, 0, 0, 1, 0.5f, 8, 65536, 1, true},          // flat mode asked for, batch smaller than one tile
   };
   int bad = 0;
-  for (const Case &c : cases) bad += run(c) != 0;
+  for (const Case &c : cases) {
+    bad += run(c, false) != 0;
+    if (!c.flat) bad += run(c, true) != 0;     // the same geometry through the generated code
+  }
   printf(bad ? "FAILED %d case(s)\n" : "all cases OK\n", bad);
   return bad ? 1 : 0;
 }

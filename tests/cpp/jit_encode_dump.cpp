@@ -1,0 +1,64 @@
+// tests/cpp/jit_encode_dump.cpp -- prints "<assembly text> | <hex dwords>" for random operands of
+// every instruction form jit_codegen.h encodes; tests/test_jit_codegen.py assembles the text with
+// llvm-mc and compares the bytes.  Test code.
+#include <cstdio>
+#include <vector>
+
+#include "jit_codegen.h"
+
+using namespace escoin::jit;
+
+static unsigned st = 99;
+static unsigned rnd(unsigned n) { st = st * 1664525u + 1013904223u; return (st >> 8) % n; }
+
+static void dump(const char *text, const std::vector<uint32_t> &c) {
+  printf("%s |", text);
+  for (uint32_t d : c) printf(" %08x", d);
+  printf("\n");
+}
+
+int main() {
+  char buf[256];
+  for (int i = 0; i < 200; ++i) {
+    std::vector<uint32_t> c;
+    const int vdst = 36 + 4 * rnd(6), vaddr = 32 + rnd(2);
+    const unsigned off = 16 * rnd(4096);
+    enc_ds_read_b128(c, vdst, vaddr, off);
+    if (off) snprintf(buf, sizeof buf, "ds_read_b128 v[%d:%d], v%d offset:%u", vdst, vdst + 3, vaddr, off);
+    else snprintf(buf, sizeof buf, "ds_read_b128 v[%d:%d], v%d", vdst, vdst + 3, vaddr);
+    dump(buf, c);
+    c.clear();
+    const int n = rnd(16);
+    enc_waitcnt_lgkm(c, n);
+    snprintf(buf, sizeof buf, "s_waitcnt lgkmcnt(%d)", n);
+    dump(buf, c);
+    c.clear();
+    // (literals that happen to be inline constants would be assembled in the short form: the
+    // generator always uses the long one, which is just as valid -- keep them out of the comparison)
+    uint32_t lit = (rnd(65536) << 16) | rnd(65536);
+    if (lit <= 64 || lit >= 0xFFFFFFF0u || lit == 0x3f000000u || lit == 0xbf000000u || lit == 0x3f800000u ||
+        lit == 0xbf800000u || lit == 0x40000000u || lit == 0xc0000000u || lit == 0x40800000u || lit == 0xc0800000u ||
+        lit == 0x3e22f983u)
+      lit = 0x12345678u;
+    const int sd = rnd(2) ? kSWeight0 : kSWeight1;
+    enc_s_mov_lit(c, sd, lit);
+    snprintf(buf, sizeof buf, "s_mov_b32 s%d, 0x%x", sd, lit);
+    dump(buf, c);
+    c.clear();
+    const int acc = 64 + 2 * rnd(96), x = 36 + 2 * rnd(12);
+    enc_pk_fma(c, acc, sd, x);
+    snprintf(buf, sizeof buf, "v_pk_fma_f32 v[%d:%d], s[%d:%d], v[%d:%d], v[%d:%d] op_sel_hi:[0,1,1]", acc, acc + 1, sd,
+             sd + 1, x, x + 1, acc, acc + 1);
+    dump(buf, c);
+  }
+  std::vector<uint32_t> c;
+  enc_setpc_return(c);
+  dump("s_setpc_b64 s[30:31]", c);
+  c.clear();
+  enc_setprio(c, 1);
+  dump("s_setprio 1", c);
+  c.clear();
+  enc_nop(c);
+  dump("s_nop 0", c);
+  return 0;
+}

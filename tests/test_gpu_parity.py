@@ -36,14 +36,29 @@ def _run(pkg, torch, desc, w, x, bias, kernel, **options):
     return out, name
 
 
-def _kernels(pkg):
-    return [pkg.KERNEL_GENERIC, pkg.KERNEL_AUTO, pkg.KERNEL_DENSE]
+def _kernels(pkg, desc=None):
+    """Every kernel family: generic (reference order), AUTO (generated code where the geometry allows,
+    jit_codegen.h), the LDS-staged stream kernel where the geometry allows, dense MFMA."""
+    ks = [pkg.KERNEL_GENERIC, pkg.KERNEL_AUTO, pkg.KERNEL_DENSE]
+    if desc is not None and _tiled_ok(desc):
+        ks.insert(2, pkg.KERNEL_TILED)
+    return ks
+
+
+def _tiled_ok(d):
+    return (d.stride_h == 1 and d.stride_w == 1 and d.dil_h == 1 and d.dil_w == 1 and d.KW <= 5 and
+            max(d.W, d.W + 2 * d.pad_w - d.KW + 1) <= 256 and d.pad_w <= 4 and d.KW - 1 - d.pad_w <= 4)
+
+
+def _fast(name):
+    """One of the two LDS-tiled kernel families (weight walk generated / LDS-staged stream)."""
+    return "tiled" in name or "jit" in name
 
 
 @pytest.mark.parametrize("path", golden_params())
 def test_golden_fixtures(pkg, torch_cuda, path):
     gd = Golden(path)
-    for kernel in _kernels(pkg):
+    for kernel in _kernels(pkg, gd.desc(pkg)):
         got, name = _run(pkg, torch_cuda, gd.desc(pkg), gd.w, gd.x, gd.bias, kernel)
         assert got.shape == gd.top.shape
         if "generic" in name:
@@ -52,8 +67,9 @@ def test_golden_fixtures(pkg, torch_cuda, path):
     # ... and through the tiling (channels per wave, images per tile, blocks) a batch of 256 / 64
     # gets: the weight stream and tile shapes of the benchmarked configurations
     for tb in (256, 64):
-        got, name = _run(pkg, torch_cuda, gd.desc(pkg), gd.w, gd.x, gd.bias, pkg.KERNEL_AUTO, tiling_batch=tb)
-        assert rel_err(got, gd.top) <= TOL, "%s via %s, tiling_batch %d" % (gd.name, name, tb)
+        for kernel in [pkg.KERNEL_AUTO] + ([pkg.KERNEL_TILED] if _tiled_ok(gd.desc(pkg)) else []):
+            got, name = _run(pkg, torch_cuda, gd.desc(pkg), gd.w, gd.x, gd.bias, kernel, tiling_batch=tb)
+            assert rel_err(got, gd.top) <= TOL, "%s via %s, tiling_batch %d" % (gd.name, name, tb)
 
 
 def _config_shapes(synth):
@@ -70,7 +86,7 @@ def test_config_layers_small_batch_vs_oracle(pkg, oracle, synth, torch_cuda):
         g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
                         s.dil_h, s.dil_w, s.group)
         want = oracle.conv_forward(g, x, w, b, gate=False, threads=4)
-        for kernel in _kernels(pkg):
+        for kernel in _kernels(pkg, pkg.ConvDesc.from_shape(s)):
             got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel)
             if "generic" in name:
                 assert np.array_equal(got, want), s.name
@@ -83,14 +99,14 @@ def _config_sets(synth):
             ("resnet50", synth.resnet50_3x3(N=256)), ("googlenet", synth.googlenet_1x1(N=256))]
 
 
-def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None):
+def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None, kernel=None):
     """Forward of the WHOLE config batch on device-generated input; images {0, 1 and 3 (inside the
     first multi-image tile), N/2, N-2, N-1} are checked against the oracle (<= 1e-4)."""
     dev = torch.device("cuda:0")
     w, b = synth.pruned_weights(s, seed), synth.bias_vector(s, seed + 1)
     own = plan is None
     if own:
-        plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_AUTO if kernel is None else kernel)
         plan.weight_align(w)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed + 2)
@@ -118,7 +134,12 @@ def test_config_layers_at_config_batch_vs_oracle(pkg, oracle, synth, torch_cuda,
     the kernel path the headline numbers are measured on."""
     shapes = dict(_config_sets(synth))[which]
     for k, s in enumerate(shapes):
+        # AUTO: the walk is code WeightAlign generated (jit_codegen.h) ...
         err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k)
+        assert "escoin_sconv_jit_kernel" in name, (s.name, name)
+        assert err <= TOL, "%s @N=%d via %s: %g" % (s.name, s.N, name, err)
+        # ... and the LDS-staged stream kernel on the same layer
+        err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k, kernel=pkg.KERNEL_TILED)
         assert "tiled" in name, (s.name, name)
         assert err <= TOL, "%s @N=%d via %s: %g" % (s.name, s.N, name, err)
         # the 3x3 layers whose planes are whole 1 KiB pieces take the instantiation that issues the
@@ -145,7 +166,7 @@ def test_per_group_dense_selection_and_conv_mode_0(pkg, oracle, synth, torch_cud
     xd, bd = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
     plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
     plan.weight_align(w)
-    assert "tiled" in plan.kernel_name and "dense_mfma" in plan.kernel_name, plan.kernel_name
+    assert _fast(plan.kernel_name) and "dense_mfma" in plan.kernel_name, plan.kernel_name
     assert rel_err(plan.forward(xd, bd).cpu().numpy(), want) <= TOL
     for mode, expect in ((pkg.CONV_MODE_LOWERED_GEMM, "escoin_dense_mfma_kernel"),
                          (pkg.CONV_MODE_LOWERED_SPARSE, "escoin_csrmm_kernel"),
@@ -155,7 +176,7 @@ def test_per_group_dense_selection_and_conv_mode_0(pkg, oracle, synth, torch_cud
         if expect:
             assert plan.kernel_name == expect
         else:
-            assert "tiled" in plan.kernel_name and "dense_mfma" in plan.kernel_name
+            assert _fast(plan.kernel_name) and "dense_mfma" in plan.kernel_name
         assert rel_err(plan.forward(xd, bd).cpu().numpy(), want) <= TOL, mode
     plan.close()
     # thresholds: 100 = never dense, 0 = any nonzero density is dense; generic kernel in a mixed layer
@@ -182,7 +203,7 @@ def test_sparsity_sweep_60_to_95(pkg, oracle, synth, torch_cuda):
         w, b, x = synth.pruned_weights(s, 1), synth.bias_vector(s, 2), synth.activations(s, 3)
         g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w)
         want = oracle.conv_forward(g, x, w, b, gate=False)
-        for kernel in _kernels(pkg):
+        for kernel in _kernels(pkg, pkg.ConvDesc.from_shape(s)):
             got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel)
             assert rel_err(got, want) <= TOL, "sparsity %g via %s" % (sp, name)
 
@@ -211,7 +232,7 @@ def test_odd_geometries(pkg, oracle, synth, torch_cuda):
                         s.dil_h, s.dil_w, s.group)
         want = oracle.conv_forward(g, x, w, b, gate=False)
         assert rel_err(want, naive_conv(x, w, b, s)) <= 1e-5
-        for kernel in _kernels(pkg):
+        for kernel in _kernels(pkg, pkg.ConvDesc.from_shape(s)):
             got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel)
             assert rel_err(got, want) <= TOL, "%s via %s: %g" % (s.name, name, rel_err(got, want))
 
@@ -266,13 +287,13 @@ def test_tile_store_epilogue_bias_relu_ragged_channels(pkg, oracle, synth, torch
         g = oracle.geom(s.C, s.H, s.W, s.M, K, K, K // 2, K // 2)
         xd = torch.from_numpy(x).to(dev)
         for relu in (False, True):
-            for tb in (0, 256):
-                plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=pkg.KERNEL_TILED, tiling_batch=tb)
+            for tb, kernel in ((0, pkg.KERNEL_TILED), (256, pkg.KERNEL_TILED), (0, pkg.KERNEL_JIT), (256, pkg.KERNEL_JIT)):
+                plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=kernel, tiling_batch=tb)
                 plan.weight_align(w)
                 for bias in (None, b):
                     got = plan.forward(xd, None if bias is None else torch.from_numpy(bias).to(dev)).cpu().numpy()
                     want = oracle.conv_forward(g, x, w, bias, relu=relu, gate=False)
-                    assert rel_err(got, want) <= TOL, (s.name, relu, tb, bias is not None, rel_err(got, want))
+                    assert rel_err(got, want) <= TOL, (s.name, relu, tb, plan.kernel_name, bias is not None, rel_err(got, want))
                 plan.close()
         k += 1
 
@@ -297,11 +318,12 @@ def test_uneven_channel_densities(pkg, oracle, synth, torch_cuda):
         b, x = synth.bias_vector(s, 810 + k), synth.activations(s, 820 + k)
         g = oracle.geom(s.C, s.H, s.W, s.M, K, K, pad, pad, 1, 1, 1, 1, group)
         want = oracle.conv_forward(g, x, w, b, relu=True, gate=False)
-        plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=True), kernel=pkg.KERNEL_TILED, tiling_batch=256)
-        plan.weight_align(w)
-        got = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
-        assert rel_err(got, want) <= TOL, (s.name, rel_err(got, want))
-        plan.close()
+        for kernel in (pkg.KERNEL_TILED, pkg.KERNEL_JIT):
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=True), kernel=kernel, tiling_batch=256)
+            plan.weight_align(w)
+            got = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+            assert rel_err(got, want) <= TOL, (s.name, plan.kernel_name, rel_err(got, want))
+            plan.close()
 
 
 def test_weight_align_from_device_and_csr_roundtrip(pkg, oracle, synth, torch_cuda):
@@ -548,10 +570,13 @@ def test_randomised_tiled_geometries(pkg, oracle, synth, torch_cuda, seed):
         # a batch of 256 -- the last two give channel groups of 4-24 per wave, several images per
         # tile and second payload quads, i.e. the streams of the benchmarked configurations
         tb = (0, 64, 256)[k % 3]
-        got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, pkg.KERNEL_AUTO,
-                         tiling_batch=tb, dense_threshold_pct=100)
-        assert rel_err(got, want) <= TOL, "%s %s tb=%d via %s: %g" % (s.name, (N, C, H, W, M, K, pad, group, sp), tb, name, rel_err(got, want))
-        checked += "tiled" in name
+        for kernel in (pkg.KERNEL_AUTO, pkg.KERNEL_TILED):      # generated code / LDS-staged stream
+            if kernel == pkg.KERNEL_TILED and not _tiled_ok(pkg.ConvDesc.from_shape(s)):
+                continue
+            got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel,
+                             tiling_batch=tb, dense_threshold_pct=100)
+            assert rel_err(got, want) <= TOL, "%s %s tb=%d via %s: %g" % (s.name, (N, C, H, W, M, K, pad, group, sp), tb, name, rel_err(got, want))
+            checked += "jit" in name
     assert checked >= 40      # nearly all of these must have gone down the tiled path
 
 
@@ -570,13 +595,15 @@ import __graft_entry__ as ge
 pkg = ge.load_package(); oracle = ge.load_oracle(); synth = pkg.synth
 s = synth.shape("chunked", 11, 6, 9, 10, 8, 3, pad=1, sparsity=0.7)
 w, b, x = synth.pruned_weights(s, 1), synth.bias_vector(s, 2), synth.activations(s, 3)
-plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_TILED)
-plan.weight_align(w)
 dev = torch.device("cuda:0")
-top = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
 g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
 want = oracle.conv_forward(g, x, w, b, gate=False)
-err = float(np.abs(top - want).max() / max(1e-6, np.abs(want).max()))
+err = 0.0
+for kernel in (pkg.KERNEL_TILED, pkg.KERNEL_JIT):
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel)
+    plan.weight_align(w)
+    top = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+    err = max(err, float(np.abs(top - want).max() / max(1e-6, np.abs(want).max())))
 print("REL_ERR %%g" %% err)
 sys.exit(0 if err <= 1e-4 else 1)
 """ % root
@@ -648,7 +675,7 @@ def test_global_batch_2048_on_one_gpu(pkg, oracle, synth, torch_cuda):
         plan.weight_align(w)
         err, name = _check_full_batch(pkg, oracle, synth, torch, s, 8100 + k, plan=plan,
                                       images=(0, 1023, 2047))
-        assert "tiled" in name and err <= TOL, "%s @N=2048 via %s: %g" % (s.name, name, err)
+        assert _fast(name) and err <= TOL, "%s @N=2048 via %s: %g" % (s.name, name, err)
         # every image through the same arithmetic: a batch made of ONE image repeated 2048 times
         # must give 2048 identical outputs (bitwise), wherever the image falls in a tile
         gen = torch.Generator(device=dev)

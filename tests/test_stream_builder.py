@@ -1,7 +1,8 @@
 """WeightAlign's MI355X half without a GPU: the tiling choice and the weight stream built by
 csrc/stream_builder.cpp are walked by a CPU emulation of the tiled kernel's dataflow
 (tests/cpp/emulate_tiled.cpp: LDS planes, lane->quad mapping, bucket walk, accumulator classes,
-shift-and-sum epilogue) and compared with a plain dense convolution on 28 geometries."""
+shift-and-sum epilogue) and compared with a plain dense convolution on 28 geometries; the same for
+the machine code csrc/jit_codegen.cpp generates, run by an interpreter of its five instruction forms."""
 import os
 import subprocess
 
@@ -13,12 +14,15 @@ def test_stream_and_tiling_against_cpu_emulation(tmp_path):
     csrc = os.path.join(ROOT, "caffe-escoin_amd", "csrc")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + csrc, "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "emulate_tiled.cpp"),
-                           os.path.join(csrc, "stream_builder.cpp")])
+                           os.path.join(csrc, "stream_builder.cpp"), os.path.join(csrc, "jit_codegen.cpp")])
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     text = out.stdout.decode()
     assert out.returncode == 0, text
     assert "all cases OK" in text
-    assert text.count("rel_err=") == 28
+    # 28 geometries through the LDS-staged weight stream, 25 of them (all but the flat-cut ones) again
+    # through the code jit_codegen.cpp generates, interpreted instruction by instruction
+    assert text.count("rel_err=") == 28 + 25
+    assert len([l for l in text.splitlines() if l.startswith("jit ")]) == 25
 
 
 def test_channel_deal_is_a_permutation_and_never_worse(tmp_path):

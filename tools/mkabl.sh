@@ -8,7 +8,9 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-re
 for s in escoin_capi sconv_generic sconv_tiled dense_mfma sconv_lowered; do
   /opt/rocm/bin/hipcc $F -c -o /tmp/abl/$s.o $s.hip &
 done
-/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -fvisibility=hidden -I. -c -o /tmp/abl/stream_builder.o stream_builder.cpp &
+for s in stream_builder jit_codegen jit_module; do
+  /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -fvisibility=hidden -I. -I../../include -c -o /tmp/abl/$s.o $s.cpp &
+done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libescoin_abl.so /tmp/abl/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libescoin_abl.so /tmp/abl/*.o -lamd_comgr
 ls -la ../libescoin_abl.so

@@ -14,5 +14,5 @@ cp $CS/sconv_tiled.hip $D/           # (a quoted #include looks beside the inclu
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$PWD/include -I$CS -Wno-unused-result \
   -Wno-inline-asm -fvisibility=hidden -DESCOIN_BUILD ${VARIANT_CFLAGS:-} -c -o $D/sconv_tiled.o $D/sconv_tiled.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o caffe-escoin_amd/libescoin_$TAG.so \
-  $CS/escoin_capi.o $CS/sconv_generic.o $D/sconv_tiled.o $CS/dense_mfma.o $CS/sconv_lowered.o $CS/stream_builder.o
+  $CS/escoin_capi.o $CS/sconv_generic.o $D/sconv_tiled.o $CS/dense_mfma.o $CS/sconv_lowered.o $CS/stream_builder.o $CS/jit_codegen.o $CS/jit_module.o -lamd_comgr
 echo "built caffe-escoin_amd/libescoin_$TAG.so ($*)"
