@@ -56,6 +56,8 @@ struct TiledConfig {
   int nbuf = 2;        // plane / staging buffers per workgroup
   bool jit = false;    // the walk is generated code (jit_codegen.h) instead of the LDS-staged stream
   long jit_rows = 0, jit_records = 0;
+  bool jit_dma = false;      // ... and its units stage the next block's planes themselves (jit_codegen.h DmaPlan)
+  int dma_period = 0;        // quads covered by the quad table (lcm of the plane size and 64)
 };
 
 }  // namespace escoin

@@ -8,12 +8,29 @@
 namespace escoin {
 namespace jit {
 
+static long gcd_l(long a, long b) { return b ? gcd_l(b, a % b) : a; }
+
+int dma_period(int qpc, int max_period, double slack, int *padded) {
+  int best = 0;
+  *padded = 0;
+  for (int q = qpc; q <= (int)(qpc * (1.0 + slack)); ++q) {
+    const long l = (long)q / gcd_l(q, 64) * 64;
+    if (l <= max_period && (best == 0 || l < best)) {
+      best = (int)l;
+      *padded = q;
+    }
+    if (best && q == qpc) break;      // the plane as it is will do
+  }
+  return best;
+}
+
 Options options_from_env() {
   Options o;
   if (const char *e = getenv("ESCOIN_JIT_DEPTH")) o.depth = std::max(1, std::min(2, atoi(e)));
   if (const char *e = getenv("ESCOIN_JIT_HOIST")) o.hoist_weight = atoi(e) != 0;
   if (const char *e = getenv("ESCOIN_JIT_PRIO_ROWS")) o.prio_rows = std::max(0, atoi(e));
   if (const char *e = getenv("ESCOIN_JIT_ABL")) o.ablate = atoi(e);
+  if (const char *e = getenv("ESCOIN_JIT_PREFETCH")) o.prefetch = atoi(e) != 0;
   return o;
 }
 
@@ -28,18 +45,99 @@ struct Row {
   std::vector<Rec> recs;
 };
 
+struct Piece {
+  uint32_t tab_off;    // byte offset of the lane-0 table entry from v34
+  uint32_t lds_off;    // LDS byte offset of the piece from the fill buffer's base
+  uint32_t soff;       // scalar offset: the channel group's bytes from the conv group's channel 0
+  int lanes;           // lanes that carry a quad of the block image (64 but for a block's last piece)
+};
+
 // The walk of one unit.  Rows are read `depth` ahead into the three input sets in rotation; LDS
-// returns data in order, so "all but the reads of the rows still ahead" is a counted wait.  A
-// set is overwritten by the read issued two rows after the one that used it: its FMAs were
-// issued (in order) before that read was.
-void emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const Options &opt) {
+// returns data in order, so every wait is a count: "all but the N operations issued after the one
+// I need" (Lds below keeps the issue order).  A set is overwritten by the read issued two rows after
+// the one that used it: its FMAs were issued (in order) before that read was.
+// `pieces`: this wave's LDS-DMA instructions for the block staged next.  A piece's table entry is
+// read at the top of one row and the instruction goes out after the wait of the next row.
+struct Lds {
+  std::vector<uint32_t> &c;
+  int issued = 0, done = 0;     // operations issued so far; operations known to have completed
+  int ablate;
+  int issue() { return issued++; }
+  void wait_for(int id) {       // operation `id` (0-based issue order) must have landed
+    if (id < done) return;
+    enc_waitcnt_lgkm(c, std::min(15, issued - 1 - id));
+    done = std::max(done, issued - std::min(15, issued - 1 - id));
+  }
+};
+
+// n_pref > 0: the unit starts with n_pref loads over the next unit's code; returns the index (in
+// `c`) of the distance literal to patch (0: none).
+size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const std::vector<Piece> &pieces,
+                 const Options &opt, int n_pref) {
+  size_t patch = 0;
+  if (n_pref > 0) {
+    enc_getpc(c, kSPref);                    // s[50:51] = address of the instruction after this one
+    patch = c.size() + 1;
+    enc_s_add_lit(c, kSPref, 0u);            // + (next unit - that address): patched
+    enc_s_addc(c, kSPref + 1, false);        // (patched to -1 for a negative distance)
+    for (int k = 0; k < n_pref; ++k) {
+      enc_global_load_dword(c, kVPrefDead, kVPrefLane, kSPref);
+      if (k + 1 < n_pref) {
+        enc_s_add_lit(c, kSPref, 4096u);
+        enc_s_addc(c, kSPref + 1, false);
+      }
+    }
+  }
   const int n = (opt.ablate & 8) ? 0 : (int)rows.size();
   const int depth = opt.depth;
+  Lds lds{c, 0, 0, opt.ablate};
+  std::vector<int> row_id(n, -1);       // issue id of a row's second read
   auto issue = [&](int k) {
     if (opt.ablate & 2) return;
     const int base = kVIn0 + 8 * (k % kInSets);
     enc_ds_read_b128(c, base, kVAddrA, rows[k].lds_off);
+    lds.issue();
     enc_ds_read_b128(c, base + 4, kVAddrB, rows[k].lds_off);
+    row_id[k] = lds.issue();
+  };
+  // pieces: table read at row t_row[p], instruction after the wait of row t_row[p] + 1
+  const int np = (int)pieces.size();
+  std::vector<int> t_row(np, 0), t_id(np, -1);
+  const int span = std::max(1, n * opt.dma.spread_pct / 100);
+  for (int p = 0; p < np; ++p) t_row[p] = np ? (int)((long)p * span / np) : 0;
+  int next_read = 0, next_issue = 0;
+  // table entries rotate through three registers; an entry may only be read into a register whose
+  // previous piece has gone out, so at most three are in flight
+  constexpr int kTabRegs = 3;
+  auto tab_reg = [](int p) {
+    static const int r[kTabRegs] = {kVTab0, kVTab1, kVTab1 + 1};
+    return r[p % kTabRegs];
+  };
+  auto read_tables = [&](int row) {     // the table entries of the pieces scheduled up to `row` (all: row < 0)
+    while (next_read < np && (row < 0 || t_row[next_read] <= row) && next_read - next_issue < kTabRegs) {
+      enc_ds_read_b32(c, tab_reg(next_read), kVTabAddr, pieces[next_read].tab_off);
+      t_id[next_read] = lds.issue();
+      ++next_read;
+    }
+  };
+  auto issue_pieces = [&](int row) {    // ... and the instructions of the pieces read at rows < `row` (all read: row < 0)
+    while (next_issue < next_read && (row < 0 || t_row[next_issue] < row)) {
+      const Piece &pc = pieces[next_issue];
+      lds.wait_for(t_id[next_issue]);
+      enc_s_add_m0_lit(c, kSFillBase, pc.lds_off);
+      enc_s_mov_lit(c, kSSoff, pc.soff);
+      if (pc.lanes < 64) {
+        const unsigned long long m = pc.lanes >= 64 ? ~0ull : ((1ull << pc.lanes) - 1);
+        enc_s_mov_lit(c, kSExecLo, (uint32_t)m);
+        enc_s_mov_lit(c, kSExecHi, (uint32_t)(m >> 32));
+      }
+      // (M0 written by the scalar unit must be at least one wait state old when an LDS-DMA
+      // instruction uses it, as in the hand-written sites: s_mov m0 / s_nop / buffer_load)
+      enc_nop(c);
+      enc_lds_dma16(c, tab_reg(next_issue), kSRsrc, kSSoff, opt.dma.nt);
+      if (pc.lanes < 64) enc_exec_all(c);
+      ++next_issue;
+    }
   };
   for (int k = 0; k < std::min(depth, n); ++k) issue(k);
   // weights alternate between two SGPR pairs; with hoisting, the s_mov of the NEXT record (of this
@@ -56,13 +154,15 @@ void emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const Opt
   if (opt.hoist_weight && !flat.empty() && !(opt.ablate & 4)) enc_s_mov_lit(c, sreg(0), flat[0]->bits);
   int prio = 0;
   for (int k = 0; k < n; ++k) {
+    read_tables(k);
     if (k + depth < n) issue(k + depth);
     if (opt.prio_rows > 0 && k % opt.prio_rows == 0) {
       prio ^= 1;
       enc_setprio(c, prio);
     }
-    const int ahead = std::min(n - 1, k + depth) - k;
-    enc_waitcnt_lgkm(c, (opt.ablate & 2) ? 0 : 2 * ahead);
+    if (opt.ablate & 2) enc_waitcnt_lgkm(c, 0);
+    else lds.wait_for(row_id[k]);
+    issue_pieces(k);
     const int xa = kVIn0 + 8 * (k % kInSets), xb = xa + 4;
     for (int j = first_of_row[k]; j < first_of_row[k + 1]; ++j) {
       if (opt.ablate & 4) {
@@ -79,16 +179,24 @@ void emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const Opt
       enc_pk_fma(c, kAccB + a + 2, sreg(j), xb + 2);
     }
   }
+  // whatever the rows did not take (short or empty units): two at a time
+  while (next_issue < np) {
+    read_tables(-1);
+    issue_pieces(-1);
+  }
   if (opt.prio_rows > 0 && prio) enc_setprio(c, 0);
   enc_setpc_return(c);
+  return patch;
 }
 
 }  // namespace
 
-Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,
-                      const std::vector<std::vector<int>> &colidx,
-                      const std::vector<std::vector<float>> &values, const Options &opt) {
+static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,
+                          const std::vector<std::vector<int>> &colidx,
+                          const std::vector<std::vector<float>> &values, const Options &opt, int n_pref,
+                          size_t *max_unit_bytes) {
   Program p;
+  std::vector<size_t> patches;
   const size_t n_units = (size_t)g.group * t.n_ocg * t.n_icb;
   p.unit_off.assign(n_units, 0u);
   p.chan.reserve((size_t)g.group * t.n_ocg * t.G);
@@ -99,6 +207,7 @@ Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std:
   }
   const int rows_per_blk = t.icb * g.KH;
   std::vector<Row> rows(rows_per_blk), live;
+  std::vector<Piece> pieces;
   for (int cg = 0; cg < g.group; ++cg)
     for (int ocg = 0; ocg < t.n_ocg; ++ocg)
       for (int blk = 0; blk < t.n_icb; ++blk) {
@@ -130,13 +239,59 @@ Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std:
           live.push_back(std::move(row));
         }
         p.n_rows += (long)live.size();
+        // this wave's pieces of the block staged while this unit runs: block blk + 1, or block 0 of
+        // the workgroup's next tile
+        pieces.clear();
+        if (opt.dma.on) {
+          const DmaPlan &d = opt.dma;
+          const int wave = ocg % d.waves;
+          const int nb = (blk + 1) % t.n_icb;
+          const int nch = std::min(t.icb, g.Cg - nb * t.icb);
+          const long total = (long)nch * d.qpc;
+          const int n_instr = (int)((total + 63) / 64);
+          const int ch_per_period = d.period / d.qpc;
+          for (int i = wave; i < n_instr; i += d.waves) {
+            const long e0 = (long)i * 64;
+            Piece pc;
+            pc.tab_off = (uint32_t)((e0 % d.period) * 4);
+            pc.lds_off = (uint32_t)i * 1024u;
+            pc.soff = (uint32_t)(((long)nb * t.icb + (e0 / d.period) * ch_per_period) * d.chan_bytes);
+            pc.lanes = (int)std::min<long>(64, total - e0);
+            pieces.push_back(pc);
+          }
+          p.n_dma += (long)pieces.size();
+        }
         while ((p.code.size() * 4) % kUnitAlign) enc_nop(p.code);
         p.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk] = (uint32_t)(p.code.size() * 4);
-        emit_unit(p.code, live, opt);
+        const size_t at = p.code.size();
+        patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref));
+        *max_unit_bytes = std::max(*max_unit_bytes, (p.code.size() - at) * 4);
       }
-  // instruction prefetch runs past the last unit's return: keep it inside the blob
-  for (int i = 0; i < 64; ++i) enc_nop(p.code);
+  // the distances: unit (cg, ocg, blk) touches the code of (cg, ocg, (blk + 1) % n_icb)
+  if (n_pref > 0)
+    for (size_t ui = 0; ui < n_units; ++ui) {
+      const size_t blk = ui % t.n_icb, nxt = ui - blk + (blk + 1) % t.n_icb;
+      const long long from = (long long)p.unit_off[ui] + 4;        // what s_getpc_b64 returned
+      const long long d = (long long)p.unit_off[nxt] - from;
+      p.code[patches[ui]] = (uint32_t)d;
+      if (d < 0) p.code[patches[ui] + 1] = 0x82000000u | ((uint32_t)(kSPref + 1) << 16) | (0xC1u << 8) | (uint32_t)(kSPref + 1);
+    }
+  // instruction prefetch and the code touches run past the last unit: keep them inside the blob
+  for (int i = 0; i < 64 + n_pref * 1024; ++i) enc_nop(p.code);
   return p;
+}
+
+Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,
+                      const std::vector<std::vector<int>> &colidx,
+                      const std::vector<std::vector<float>> &values, const Options &opt) {
+  size_t max_unit = 0;
+  Program p = build_pass(g, t, rowptr, colidx, values, opt, 0, &max_unit);
+  if (!opt.prefetch || p.overflow) return p;
+  // every unit carries the same number of touches: enough for the longest unit (its own touches included)
+  int n_pref = 1;
+  while ((size_t)n_pref * 4096 < max_unit + 16 + (size_t)n_pref * 20) ++n_pref;
+  max_unit = 0;
+  return build_pass(g, t, rowptr, colidx, values, opt, n_pref, &max_unit);
 }
 
 }  // namespace jit

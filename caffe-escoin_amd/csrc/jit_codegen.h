@@ -33,6 +33,15 @@
 //   v[64:159] / v[160:255]         tile-A / tile-B accumulators, as in the LDS-staged kernel
 //   s40 / s42 (pairs s[40:41], s[42:43])   weights, alternating
 //   s[30:31] return address (the unit is entered with s_swappc_b64)
+// Plane DMA from inside the code (DmaPlan, layers with one wave per oc-group): while a unit walks
+// block k, ITS wave's share of the LDS-DMA instructions that stage block k + 1 (or the next tile's
+// block 0) is part of the unit's code, spread over its first rows -- in a burst at the block top an
+// LDS-DMA instruction holds its wave for ~100 cycles, among FMAs for 5-20 -- with
+// everything static: which 1 KiB piece, its LDS address, its channel (the scalar offset), its
+// table entry (a ds_read_b32 at an immediate offset).  Extra registers:
+//   v34  LDS byte address of this lane's entry 0 in the quad table of the tile being STAGED
+//   v35, v60, v61   table entries (in rotation), s[44:47] the bottom blob's buffer descriptor (zero
+//   records when nothing is left to stage), s48 LDS byte address of the buffer being filled, s49 scratch
 #ifndef ESCOIN_JIT_CODEGEN_H_
 #define ESCOIN_JIT_CODEGEN_H_
 
@@ -49,6 +58,8 @@ constexpr int kVIn0 = 36;          // input sets at 36, 44, 52
 constexpr int kInSets = 3;
 constexpr int kAccA = 64, kAccB = 160;
 constexpr int kSWeight0 = 40, kSWeight1 = 42;
+constexpr int kVTabAddr = 34, kVTab0 = 35, kVTab1 = 60;
+constexpr int kSRsrc = 44, kSFillBase = 48, kSSoff = 49;
 constexpr int kUnitAlign = 64;     // bytes: a unit starts on an instruction-cache line
 
 // ---- instruction encoders (gfx950; checked against llvm-mc in tests/test_jit_codegen.py) ----
@@ -70,9 +81,65 @@ inline void enc_pk_fma(std::vector<uint32_t> &c, int acc, int sw, int x) {
   c.push_back(0xD3B04000u | (uint32_t)acc);
   c.push_back((uint32_t)sw | ((256u + (uint32_t)x) << 9) | ((256u + (uint32_t)acc) << 18) | (2u << 27));
 }
+// ds_read_b32 v<vdst>, v<vaddr> offset:<off>
+inline void enc_ds_read_b32(std::vector<uint32_t> &c, int vdst, int vaddr, unsigned off) {
+  c.push_back(0xD86C0000u | (off & 0xFFFFu));
+  c.push_back(((uint32_t)vdst << 24) | (uint32_t)vaddr);
+}
+// s_add_u32 m0, s<ssrc>, <32-bit literal>
+inline void enc_s_add_m0_lit(std::vector<uint32_t> &c, int ssrc, uint32_t lit) {
+  c.push_back(0x807CFF00u | (uint32_t)ssrc);
+  c.push_back(lit);
+}
+constexpr int kSExecLo = 0x7E, kSExecHi = 0x7F;          // s_mov_b32 exec_lo / exec_hi through enc_s_mov_lit
+inline void enc_exec_all(std::vector<uint32_t> &c) { c.push_back(0xBEFE01C1u); }       // s_mov_b64 exec, -1
+// buffer_load_dwordx4 v<vaddr>, s[srsrc:srsrc+3], s<soff> offen [nt] lds   (LDS address in M0)
+inline void enc_lds_dma16(std::vector<uint32_t> &c, int vaddr, int srsrc, int soff, bool nt) {
+  c.push_back(nt ? 0xE05F1000u : 0xE05D1000u);
+  c.push_back((uint32_t)vaddr | ((uint32_t)(srsrc >> 2) << 16) | ((uint32_t)soff << 24));
+}
+inline void enc_getpc(std::vector<uint32_t> &c, int sdst) { c.push_back(0xBE801C00u | ((uint32_t)sdst << 16)); }   // s_getpc_b64 s[sdst:sdst+1]
+// s_add_u32 s<sd>, s<sd>, <literal> ; s_addc_u32 s<sd+1>, s<sd+1>, 0 | -1
+inline void enc_s_add_lit(std::vector<uint32_t> &c, int sd, uint32_t lit) {
+  c.push_back(0x8000FF00u | ((uint32_t)sd << 16) | (uint32_t)sd);
+  c.push_back(lit);
+}
+inline void enc_s_addc(std::vector<uint32_t> &c, int sd, bool minus_one) {
+  c.push_back(0x82000000u | ((uint32_t)sd << 16) | ((minus_one ? 0xC1u : 0x80u) << 8) | (uint32_t)sd);
+}
+// global_load_dword v<vdst>, v<vaddr>, s[saddr:saddr+1]
+inline void enc_global_load_dword(std::vector<uint32_t> &c, int vdst, int vaddr, int saddr) {
+  c.push_back(0xDC508000u);
+  c.push_back((uint32_t)vaddr | ((uint32_t)saddr << 16) | ((uint32_t)vdst << 24));
+}
 inline void enc_setpc_return(std::vector<uint32_t> &c) { c.push_back(0xBE801D1Eu); }   // s_setpc_b64 s[30:31]
 inline void enc_setprio(std::vector<uint32_t> &c, int p) { c.push_back(0xBF8F0000u | (uint32_t)(p & 3)); }
 inline void enc_nop(std::vector<uint32_t> &c) { c.push_back(0xBF800000u); }
+
+// What the generated code must know to stage the next block's planes itself.
+struct DmaPlan {
+  bool on = false;
+  int qpc = 0;              // quads per channel plane in LDS (Tiling::plane_ch_floats / 4)
+  int period = 0;           // lcm(qpc, 64): the quad table covers this many quads = period / qpc channels
+  uint32_t chan_bytes = 0;  // bytes between two channel planes of the bottom blob (H * W * 4)
+  int waves = 8;            // waves sharing the fill (piece i is issued by wave i % waves)
+  bool nt = false;          // non-temporal loads (the layer's input is read by one workgroup column)
+  int spread_pct = 70;      // the pieces go out over the first this many percent of a unit's rows
+};
+
+// Smallest period lcm(qpc', 64) <= max_period over qpc' in [qpc, qpc * (1 + slack)]: *padded = qpc'
+// (0: none).  A plane may be padded by a few quads so that the table stays small.
+int dma_period(int qpc, int max_period, double slack, int *padded);
+
+// Code prefetch: a unit's code is megabytes away from being cache resident when its layer runs once
+// per forward pass (a step of the ResNet set touches 2.8 GB between two launches of a layer), and
+// an instruction-cache miss that goes to HBM stalls its wave for microseconds.  Every unit therefore
+// starts by touching the lines of the unit its wave runs NEXT (the next block's; after the last
+// block, block 0's, for the next tile) with plain loads into a dead register -- 64 lanes x 64 bytes
+// per instruction -- so that they are in L2 a block later.  Position independent: s_getpc_b64 plus the
+// distance, patched in once every unit's place is known.
+//   v63 = lane * 64 (set by the caller), v62 dead, s[50:51] scratch
+constexpr int kVPrefDead = 62, kVPrefLane = 63, kSPref = 50;
 
 struct Options {
   int depth = 2;          // rows read ahead (1 or 2; three input sets allow 2)
@@ -80,6 +147,8 @@ struct Options {
   int prio_rows = 0;      // > 0: s_setprio alternates every this many rows (0: never)
   int ablate = 0;         // timing experiments only (ESCOIN_JIT_ABL; wrong results): 1 no FMAs, 2 no LDS
                           // reads, 4 no weight moves, 8 empty units
+  DmaPlan dma;
+  int prefetch = 1;       // touch the next unit's code (above)
 };
 Options options_from_env();
 
@@ -87,7 +156,7 @@ struct Program {
   std::vector<uint32_t> code;       // every unit, back to back, each aligned to kUnitAlign bytes
   std::vector<uint32_t> unit_off;   // [conv group][n_ocg][n_icb]: byte offset of the unit's entry
   std::vector<uint32_t> chan;       // slot -> output channel, as WeightStream::chan
-  long n_rows = 0, n_records = 0;
+  long n_rows = 0, n_records = 0, n_dma = 0;
   bool overflow = false;            // an LDS offset does not fit the instruction's 16-bit field
 };
 

@@ -212,6 +212,23 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, 
   return best;
 }
 
+Tiling repad_planes(const ConvGeom &g, Tiling t, int qpc, int lds_budget_bytes) {
+  if (!t.ok || qpc * 4 < t.plane_ch_floats) return t;
+  t.plane_ch_floats = qpc * 4;
+  const int per_ch = t.plane_ch_floats * 4;
+  lds_budget_bytes = std::min(lds_budget_bytes, 64 * 1024);
+  int icb = lds_budget_bytes / per_ch;
+  if (icb < 1) {
+    t.ok = false;
+    return t;
+  }
+  icb = std::min(icb, g.Cg);
+  t.n_icb = (g.Cg + icb - 1) / icb;
+  t.icb = (g.Cg + t.n_icb - 1) / t.n_icb;
+  t.planes_bytes = t.icb * per_ch;
+  return t;
+}
+
 namespace {
 struct Rec {
   float val;

@@ -69,6 +69,10 @@ struct Tiling {
 // channels x images per workgroup) the one with the lowest estimated launch time is taken.
 Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu = 256);
 
+// The same tiling with channel planes of `qpc` quads in LDS (>= the tiling's own: padding quads are
+// staged like rows past the image) and the input-channel blocks recomputed for the budget.
+Tiling repad_planes(const ConvGeom &g, Tiling t, int qpc, int lds_budget_bytes);
+
 // ---- the weight stream: staged in LDS with the planes, values read as broadcast quads ---------
 //
 // One unit per (conv group, oc-group, input-channel block), in two parts:

@@ -34,23 +34,37 @@ struct JitWave {
   std::vector<float> v;   // [64][256]
   JitWave() : v(64 * 256, 0.f) {}
 };
-struct PendingRead { int vdst; std::vector<float> data; };   // data: [64][4]
+struct PendingRead { int vdst; int n; std::vector<float> data; };   // data: [64][n]
+struct DmaPiece { uint32_t m0, soff; unsigned long long exec; std::vector<uint32_t> voff; bool nt; };
+struct JitPref { long long base = -1; int touches = 0; };
+static size_t last_return_pc = 0;   // code touches of a unit: first address, count
+struct JitDmaCtx {
+  const std::vector<uint32_t> *tabx = nullptr;   // the quad table of the tile being staged (period entries)
+  uint32_t fill_base = 0;
+  std::vector<DmaPiece> issued;
+};
 
 static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w, const std::vector<float> &lds,
-                        const std::vector<uint32_t> &laneA /* LDS byte address of the lane's tile-A quad */) {
+                        const std::vector<uint32_t> &laneA /* LDS byte address of the lane's tile-A quad */,
+                        JitDmaCtx *dma = nullptr, JitPref *pref = nullptr) {
+  long long s50 = -1;
   std::vector<PendingRead> pending;
   uint32_t sreg[128] = {0};
+  uint32_t m0 = 0;
+  unsigned long long exec = ~0ull;
+  bool tab_unissued[256] = {false};     // a table entry was read into this register and its piece has not gone out
+  if (dma) sreg[48] = dma->fill_base;
   auto retire_to = [&](size_t keep) {
     while (pending.size() > keep) {
       const PendingRead &r = pending.front();
       for (int lane = 0; lane < 64; ++lane)
-        for (int e = 0; e < 4; ++e) w.v[(size_t)lane * 256 + r.vdst + e] = r.data[lane * 4 + e];
+        for (int e = 0; e < r.n; ++e) w.v[(size_t)lane * 256 + r.vdst + e] = r.data[lane * r.n + e];
       pending.erase(pending.begin());
     }
   };
   auto is_pending = [&](int reg) {
     for (const PendingRead &r : pending)
-      if (reg >= r.vdst && reg < r.vdst + 4) return true;
+      if (reg >= r.vdst && reg < r.vdst + r.n) return true;
     return false;
   };
   for (long steps = 0; steps < 100000000; ++steps) {
@@ -58,7 +72,27 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
     const uint32_t d0 = code[pc / 4];
     if (d0 == 0xBE801D1Eu) {   // s_setpc_b64 s[30:31]
       if (!pending.empty()) { printf("jit: unit returns with LDS reads pending\n"); return 3; }
+      if (exec != ~0ull) { printf("jit: unit returns with a partial EXEC\n"); return 3; }
+      last_return_pc = pc;
       return 0;
+    }
+    if (d0 == 0xBEFE01C1u) { exec = ~0ull; pc += 4; continue; }   // s_mov_b64 exec, -1
+    if (d0 == 0xBEB21C00u) { s50 = (long long)pc + 4; pc += 4; continue; }   // s_getpc_b64 s[50:51]
+    if (d0 == 0x8032FF32u) { s50 += (long long)(int32_t)code[pc / 4 + 1]; pc += 8; continue; }   // s_add_u32 s50, s50, lit (+ the carry below)
+    if (d0 == 0x82338033u || d0 == 0x8233C133u) {   // s_addc_u32 s51, s51, 0 | -1: the sign of the literal just added
+      const bool neg = (int32_t)code[pc / 4 - 1] < 0;
+      if (neg != (d0 == 0x8233C133u)) { printf("jit: carry word does not match the sign of the distance\n"); return 3; }
+      pc += 4;
+      continue;
+    }
+    if (d0 == 0xDC508000u) {   // global_load_dword v62, v63, s[50:51]: a touch of the next unit's code
+      if (code[pc / 4 + 1] != (0x3Fu | (50u << 16) | (62u << 24)) || !pref || s50 < 0) { printf("jit: bad code touch\n"); return 3; }
+      if (s50 + 4096 > (long long)code.size() * 4) { printf("jit: code touch past the blob\n"); return 3; }
+      if (pref->touches == 0) pref->base = s50;
+      else if (s50 != pref->base + 4096ll * pref->touches) { printf("jit: code touches not contiguous\n"); return 3; }
+      pref->touches++;
+      pc += 8;
+      continue;
     }
     if ((d0 & 0xFFFF0000u) == 0xBF8C0000u) {   // s_waitcnt
       if ((d0 & 0xF0FFu) != 0xC07Fu) { printf("jit: unexpected s_waitcnt fields\n"); return 3; }
@@ -75,6 +109,7 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       if (is_pending(vdst)) { printf("jit: read into a register with a read pending\n"); return 3; }
       PendingRead r;
       r.vdst = vdst;
+      r.n = 4;
       r.data.resize(64 * 4);
       for (int lane = 0; lane < 64; ++lane) {
         const size_t a = ((size_t)laneA[lane] + (vaddr == 33 ? 1024u : 0u) + off) / 4;
@@ -85,8 +120,51 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       pc += 8;
       continue;
     }
-    if ((d0 & 0xFF80FFFFu) == 0xBE8000FFu) {   // s_mov_b32 s, literal
-      sreg[(d0 >> 16) & 0x7F] = d1;
+    if ((d0 & 0xFF80FFFFu) == 0xBE8000FFu) {   // s_mov_b32 s, literal (also exec_lo / exec_hi)
+      const int sd = (d0 >> 16) & 0x7F;
+      if (sd == 0x7E) exec = (exec & 0xFFFFFFFF00000000ull) | d1;
+      else if (sd == 0x7F) exec = (exec & 0xFFFFFFFFull) | ((unsigned long long)d1 << 32);
+      else sreg[sd] = d1;
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFFFF0000u) == 0xD86C0000u) {   // ds_read_b32: an entry of the quad table
+      const unsigned off = d0 & 0xFFFFu;
+      const int vdst = (int)(d1 >> 24), vaddr = (int)(d1 & 0xFF);
+      if (!dma || vaddr != 34 || (vdst != 35 && (vdst < 60 || vdst > 61)) || (off & 3)) { printf("jit: bad ds_read_b32\n"); return 3; }
+      if (tab_unissued[vdst]) { printf("jit: table register v%d overwritten before its piece went out\n", vdst); return 3; }
+      tab_unissued[vdst] = true;
+      if (is_pending(vdst)) { printf("jit: table read into a register with a read pending\n"); return 3; }
+      PendingRead r;
+      r.vdst = vdst;
+      r.n = 1;
+      r.data.resize(64);
+      for (int lane = 0; lane < 64; ++lane) {
+        const size_t e = off / 4 + lane;
+        if (e >= dma->tabx->size()) { printf("jit: table read past the table\n"); return 3; }
+        uint32_t u = (*dma->tabx)[e];
+        std::memcpy(&r.data[lane], &u, 4);
+      }
+      pending.push_back(r);
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFFFFFF00u) == 0x807CFF00u) {   // s_add_u32 m0, s, literal
+      m0 = sreg[d0 & 0xFF] + d1;
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFFFDFFFFu) == 0xE05D1000u) {   // buffer_load_dwordx4 v, s[44:47], s49 offen [nt] lds
+      const int vaddr = (int)(d1 & 0xFF), srsrc = (int)((d1 >> 16) & 0x1F) * 4, soff = (int)(d1 >> 24);
+      if (!dma || srsrc != 44 || soff != 49 || (vaddr != 35 && (vaddr < 60 || vaddr > 61))) { printf("jit: bad LDS-DMA operands\n"); return 3; }
+      if (!tab_unissued[vaddr]) { printf("jit: LDS-DMA through v%d without a fresh table entry\n", vaddr); return 3; }
+      tab_unissued[vaddr] = false;
+      if (is_pending(vaddr)) { printf("jit: LDS-DMA issued before its table entry landed\n"); return 3; }
+      DmaPiece pcs;
+      pcs.m0 = m0; pcs.soff = sreg[49]; pcs.exec = exec; pcs.nt = (d0 >> 17) & 1;
+      pcs.voff.resize(64);
+      for (int lane = 0; lane < 64; ++lane) std::memcpy(&pcs.voff[lane], &w.v[(size_t)lane * 256 + vaddr], 4);
+      dma->issued.push_back(pcs);
       pc += 8;
       continue;
     }
@@ -141,11 +219,24 @@ static int run(const Case &cs, bool use_jit) {
   }
   WeightStream ws2 = build_stream(g, t, rp, ci, va);
   jit::Program jp;
+  jit::DmaPlan jdma;
   if (use_jit) {
     jit::Options jo;
     jo.depth = 1 + (cs.N & 1);            // both read-ahead depths and both weight placements get exercised
     jo.hoist_weight = (cs.C >> 1) & 1;
     jo.prio_rows = (cs.M & 1) ? 2 : 0;
+    // plane DMA from inside the code wherever one wave owns an oc-group (whatever the table's size: the
+    // product bounds it, the emulation does not need to)
+    if (t.pix_waves == 1 && t.waves == 8) {
+      int padded = 0;
+      jo.dma.period = jit::dma_period(t.plane_ch_floats / 4, 1 << 24, 0.0, &padded);
+      jo.dma.on = jo.dma.period > 0 && padded == t.plane_ch_floats / 4;
+      jo.dma.qpc = t.plane_ch_floats / 4;
+      jo.dma.chan_bytes = (uint32_t)(cs.H * cs.W * 4);
+      jo.dma.nt = (cs.N & 2) != 0;
+      jo.dma.spread_pct = 40 + 10 * (cs.M % 5);
+    }
+    jdma = jo.dma;
     jp = jit::build_program(g, t, rp, ci, va, jo);
     if (jp.overflow) { printf("jit: LDS offset overflow\n"); return 3; }
     if (jp.n_records != ws2.n_records) { printf("jit: %ld records, stream has %ld\n", jp.n_records, ws2.n_records); return 3; }
@@ -185,6 +276,9 @@ static int run(const Case &cs, bool use_jit) {
         }
     }
 
+  std::vector<JitPref> pref_of(use_jit ? jp.unit_off.size() : 0);
+  std::vector<size_t> unit_end(use_jit ? jp.unit_off.size() : 0, 0);
+  long dma_checked = 0;
   std::vector<float> got((size_t)g.N * g.M * g.OH * g.OW, -777.f);
   std::vector<int> written(got.size(), 0);
   const int n_tiles = t.flat ? t.bands : t.band_mode ? g.N * t.bands : (g.N + t.nseg - 1) / t.nseg;
@@ -243,8 +337,54 @@ static int run(const Case &cs, bool use_jit) {
               }
               const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
               if (jp.unit_off[ui] % jit::kUnitAlign) { printf("jit: unit not aligned\n"); return 3; }
-              const int rc = jit_run_unit(jp.code, jp.unit_off[ui], jw, lds, laneA);
+              // the quad table of "the tile being staged": synthetic offsets, some of them the
+              // out-of-range marker; the pieces the unit issues must cover this wave's share of block
+              // blk + 1's image exactly, every lane from the right table entry and channel
+              std::vector<uint32_t> tab(jdma.on ? jdma.qpc : 0), tabx(jdma.on ? jdma.period : 0);
+              for (size_t f = 0; f < tab.size(); ++f) tab[f] = (f % 7 == 3) ? 0xFFFFFFF0u : (uint32_t)(4096 + 16 * f);
+              for (size_t e = 0; e < tabx.size(); ++e) {
+                const size_t c = e / jdma.qpc, f = e % jdma.qpc;
+                tabx[e] = tab[f] == 0xFFFFFFF0u ? 0xFFFFFFF0u : tab[f] + (uint32_t)(c * jdma.chan_bytes);
+              }
+              JitDmaCtx dctx;
+              dctx.tabx = &tabx;
+              dctx.fill_base = 0x10000u * (unsigned)((blk + 1) & 1);
+              JitPref pref;
+              const int rc = jit_run_unit(jp.code, jp.unit_off[ui], jw, lds, laneA, jdma.on ? &dctx : nullptr, &pref);
               if (rc) return rc;
+              pref_of[ui] = pref;
+              unit_end[ui] = last_return_pc + 4;
+              if (jdma.on) {
+                const int nb = (blk + 1) % t.n_icb;
+                const int nch = std::min(t.icb, g.Cg - nb * t.icb);
+                const long total = (long)nch * jdma.qpc;
+                const int n_instr = (int)((total + 63) / 64);
+                std::vector<int> seen(n_instr, 0);
+                for (const DmaPiece &pcs : dctx.issued) {
+                  const uint32_t rel = pcs.m0 - dctx.fill_base;
+                  if (rel % 1024 || (int)(rel / 1024) >= n_instr) { printf("jit dma: bad LDS address\n"); return 3; }
+                  const int i = (int)(rel / 1024);
+                  if (i % 8 != ocg % 8) { printf("jit dma: piece %d issued by wave %d\n", i, ocg % 8); return 3; }
+                  seen[i]++;
+                  if (pcs.nt != jdma.nt) { printf("jit dma: nt flag\n"); return 3; }
+                  for (int lane = 0; lane < 64; ++lane) {
+                    const long e = (long)i * 64 + lane;
+                    const bool on = (pcs.exec >> lane) & 1ull;
+                    if (on != (e < total)) { printf("jit dma: lane %d of piece %d: exec %d, in image %d\n", lane, i, (int)on, (int)(e < total)); return 3; }
+                    if (!on) continue;
+                    const long icl = e / jdma.qpc, f = e % jdma.qpc;
+                    if (tab[f] == 0xFFFFFFF0u) {
+                      if (pcs.voff[lane] != 0xFFFFFFF0u) { printf("jit dma: halo quad not marked\n"); return 3; }
+                    } else {
+                      const uint32_t want_g = tab[f] + (uint32_t)(((long)nb * t.icb + icl) * jdma.chan_bytes);
+                      if (pcs.voff[lane] == 0xFFFFFFF0u || pcs.voff[lane] + pcs.soff != want_g) { printf("jit dma: piece %d lane %d reads %u, want %u\n", i, lane, pcs.voff[lane] + pcs.soff, want_g); return 3; }
+                    }
+                  }
+                }
+                for (int i = ocg % 8; i < n_instr; i += 8)
+                  if (seen[i] != 1) { printf("jit dma: piece %d issued %d times\n", i, seen[i]); return 3; }
+                dma_checked += (long)dctx.issued.size();
+              }
               for (int lane = 0; lane < 64; ++lane)
                 for (int r = 0; r < kAccAll; ++r) acc[((size_t)wave * 64 + lane) * kAccAll + r] = jw.v[(size_t)lane * 256 + 64 + r];
             } else {
@@ -350,6 +490,17 @@ static int run(const Case &cs, bool use_jit) {
           }
         }
       }
+  // every unit touched the code of the unit its wave runs next, from its first byte to its return
+  if (use_jit)
+    for (size_t ui = 0; ui < jp.unit_off.size(); ++ui) {
+      if (!unit_end[ui]) continue;     // (never run: an oc-group slot past the last channel)
+      const size_t blk = ui % t.n_icb, nxt = ui - blk + (blk + 1) % t.n_icb;
+      const JitPref &pf = pref_of[ui];
+      if (pf.touches < 1 || pf.base != (long long)jp.unit_off[nxt] || (size_t)pf.base + 4096ull * pf.touches < unit_end[nxt]) {
+        printf("jit: code touches %lld+%d do not cover the next unit [%u, %zu)\n", pf.base, pf.touches, jp.unit_off[nxt], unit_end[nxt]);
+        return 3;
+      }
+    }
   double maxerr = 0, maxref = 0;
   for (size_t i = 0; i < got.size(); ++i) {
     if (written[i] != 1) { printf("output %zu written %d times\n", i, written[i]); return 4; }
@@ -358,10 +509,11 @@ static int run(const Case &cs, bool use_jit) {
   }
   const double rel = maxerr / std::fmax(1e-6, maxref);
   printf("%sN%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
-         "groups=%ld recs=%ld recs/group=%.2f rel_err=%.2e\n",
+         "groups=%ld recs=%ld recs/group=%.2f dma=%ld rel_err=%.2e\n",
          use_jit ? "jit " : "", cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.S4, t.G,
          t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes,
-         ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, rel);
+         ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, dma_checked, rel);
+  if (use_jit && jdma.on && dma_checked == 0) { printf("jit dma: nothing was checked\n"); return 3; }
   return rel <= 1e-5 ? 0 : 1;
 }
 
@@ -392,6 +544,7 @@ int main() {
       {2, 5, 56, 56, 70, 3, 3, 1, 1, 1, 0.9f, 8, 65536, 256},   // empty chip: one channel per wave, 9 passes
       {5, 30, 7, 7, 48, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 256},    // empty chip, pointwise
       {40, 16, 7, 7, 64, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 8},     // 8 CUs: images per workgroup vs passes
+      {1, 48, 56, 56, 64, 1, 1, 0, 0, 1, 0.97f, 8, 65536, 256}, // one channel per wave, units of 0-2 rows: the code's own plane DMA goes out in the tail
       {9, 12, 28, 28, 20, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 1, true},       // pointwise, H*W % 4 == 0: flat mode
       {5, 10, 14, 14, 40, 1, 1, 0, 0, 2, 0.8f, 8, 65536, 1, true},       // flat mode, groups, images straddling rows
       {3, 6, 4, 4, 12, 1, 1, 0, 0, 1, 0.5f, 8, 65536, 1, true},          // flat mode asked for, batch smaller than one tile

@@ -51,7 +51,56 @@ int main() {
              sd + 1, x, x + 1, acc, acc + 1);
     dump(buf, c);
   }
+  for (int i = 0; i < 40; ++i) {
+    std::vector<uint32_t> c;
+    const int vd = (i & 1) ? kVTab1 + (int)rnd(2) : kVTab0;
+    const unsigned off = 4 * rnd(16384);
+    enc_ds_read_b32(c, vd, kVTabAddr, off);
+    if (off) snprintf(buf, sizeof buf, "ds_read_b32 v%d, v%d offset:%u", vd, kVTabAddr, off);
+    else snprintf(buf, sizeof buf, "ds_read_b32 v%d, v%d", vd, kVTabAddr);
+    dump(buf, c);
+    c.clear();
+    const uint32_t lit = 1024u * (1 + rnd(60)) + 65u;
+    enc_s_add_m0_lit(c, kSFillBase, lit);
+    snprintf(buf, sizeof buf, "s_add_u32 m0, s%d, 0x%x", kSFillBase, lit);
+    dump(buf, c);
+    c.clear();
+    enc_s_mov_lit(c, kSSoff, 0x00abc123u + i);
+    snprintf(buf, sizeof buf, "s_mov_b32 s%d, 0x%x", kSSoff, 0x00abc123u + i);
+    dump(buf, c);
+    c.clear();
+    enc_s_mov_lit(c, kSExecLo, 0x0000ffffu + i * 4096u);
+    snprintf(buf, sizeof buf, "s_mov_b32 exec_lo, 0x%x", 0x0000ffffu + i * 4096u);
+    dump(buf, c);
+    c.clear();
+    enc_s_mov_lit(c, kSExecHi, 0x00ffff00u + i * 4096u);
+    snprintf(buf, sizeof buf, "s_mov_b32 exec_hi, 0x%x", 0x00ffff00u + i * 4096u);
+    dump(buf, c);
+    c.clear();
+    enc_lds_dma16(c, vd, kSRsrc, kSSoff, (i & 2) != 0);
+    snprintf(buf, sizeof buf, "buffer_load_dwordx4 v%d, s[%d:%d], s%d offen%s lds", vd, kSRsrc, kSRsrc + 3, kSSoff, (i & 2) ? " nt" : "");
+    dump(buf, c);
+    c.clear();
+    enc_s_add_lit(c, kSPref, 0x1000u + 77u * i);
+    snprintf(buf, sizeof buf, "s_add_u32 s%d, s%d, 0x%x", kSPref, kSPref, 0x1000u + 77u * i);
+    dump(buf, c);
+  }
   std::vector<uint32_t> c;
+  enc_exec_all(c);
+  dump("s_mov_b64 exec, -1", c);
+  c.clear();
+  enc_getpc(c, kSPref);
+  dump("s_getpc_b64 s[50:51]", c);
+  c.clear();
+  enc_s_addc(c, kSPref + 1, false);
+  dump("s_addc_u32 s51, s51, 0", c);
+  c.clear();
+  enc_s_addc(c, kSPref + 1, true);
+  dump("s_addc_u32 s51, s51, -1", c);
+  c.clear();
+  enc_global_load_dword(c, kVPrefDead, kVPrefLane, kSPref);
+  dump("global_load_dword v62, v63, s[50:51]", c);
+  c.clear();
   enc_setpc_return(c);
   dump("s_setpc_b64 s[30:31]", c);
   c.clear();

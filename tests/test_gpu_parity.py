@@ -135,7 +135,7 @@ def test_config_layers_at_config_batch_vs_oracle(pkg, oracle, synth, torch_cuda,
     shapes = dict(_config_sets(synth))[which]
     for k, s in enumerate(shapes):
         # AUTO: the walk is code WeightAlign generated (jit_codegen.h) ...
-        err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k)
+        err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k, kernel=pkg.KERNEL_JIT)
         assert "escoin_sconv_jit_kernel" in name, (s.name, name)
         assert err <= TOL, "%s @N=%d via %s: %g" % (s.name, s.N, name, err)
         # ... and the LDS-staged stream kernel on the same layer

@@ -19,13 +19,16 @@ import random
 import sys
 
 ACC_A, ACC_B = 64, 160
-SIZES_KB = [32, 128, 512, 2048, 8192]
+SIZES_KB = [32, 2048]
+NO_READS = NO_SMOV = NO_FMA = False     # ablations of the instruction mix (variants, see main)
 
 
 def group(rng, n, phase):
     """One input row with n nonzeros, the way generated code would look."""
     xa, xb = (36, 40) if phase == 0 else (44, 48)
     off = rng.randrange(0, 56) * 1024 + rng.randrange(0, 4) * 256
+    if NO_READS:
+        return []
     L = ["ds_read_b128 v[%d:%d], v1 offset:%d" % (xa, xa + 3, off),
          "ds_read_b128 v[%d:%d], v1 offset:%d" % (xb, xb + 3, off + 1024)]
     return L
@@ -36,7 +39,10 @@ def records(rng, n, phase):
     L = []
     for r in range(n):
         a = 4 * rng.randrange(0, 24)
-        L.append("s_mov_b32 s40, 0x%08x" % (0x3c000000 + rng.randrange(1, 1 << 20)))
+        if not NO_SMOV:
+            L.append("s_mov_b32 s40, 0x%08x" % (0x3c000000 + rng.randrange(1, 1 << 20)))
+        if NO_FMA:
+            continue
         for (acc, x) in ((ACC_A + a, xa), (ACC_A + a + 2, xa + 2), (ACC_B + a, xb), (ACC_B + a + 2, xb + 2)):
             L.append("v_pk_fma_f32 v[%d:%d], s[40:41], v[%d:%d], v[%d:%d] op_sel_hi:[0,1,1]"
                      % (acc, acc + 1, x, x + 1, acc, acc + 1))
@@ -52,7 +58,7 @@ def block(seed, ngroups=16):
     for k in range(ngroups):
         if k + 1 < ngroups:
             L += group(rng, ns[k + 1], (k + 1) & 1)
-            L.append("s_waitcnt lgkmcnt(2)")
+            L.append("s_waitcnt lgkmcnt(%d)" % (0 if NO_READS else 2))
         else:
             L.append("s_waitcnt lgkmcnt(0)")
         L += records(rng, ns[k], k & 1)
@@ -67,7 +73,7 @@ def size_of(lines):
     return n
 
 
-def kernel(size_kb, nseg=8):
+def kernel(size_kb, nseg=8, tag=""):
     blk, nrec = block(7)
     bsz = size_of(blk)
     seg_target = size_kb * 1024 // nseg
@@ -107,21 +113,23 @@ def kernel(size_kb, nseg=8):
     text = "".join('      "%s\\n"\n' % ln for ln in asm)
     clob = ", ".join('"v%d"' % i for i in range(36, 256))
     src = """
-__global__ void __launch_bounds__(512) k_is%d(float *out, int iters, int own) {
+__global__ void __launch_bounds__(512) k_is%s(float *out, int iters, int own, unsigned long long *clk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int i = threadIdx.x; i < 16384; i += 512) lds[i] = (float)(i & 7) * 1e-3f;
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int seg = own ? wave : 0;
   const unsigned lb = (threadIdx.x & 63) * 16;
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   asm volatile("v_mov_b32 v1, %%[lb]\\n"
 %s      :: [seg] "s"(seg), [iters] "s"(iters), [lb] "v"(lb)
       : "memory", "scc", "s40", "s41", "s42", "s44", "s46", "s47", "s48", "s49", "v1", %s);
+  if (threadIdx.x == 0) { clk[2 * blockIdx.x] = __builtin_readcyclecounter() - c0; clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
   float r;
   asm volatile("v_mov_b32 %%0, v64" : "=v"(r));
   if (r == 12345.f) out[threadIdx.x] = r;
 }
-""" % (size_kb, text, clob)
+""" % ("%d%s" % (size_kb, tag), text, clob)
     return src, reps * nrec, seg_bytes * nseg
 
 
@@ -138,38 +146,45 @@ def main():
     out = sys.stdout
     out.write(HEADER)
     table = []
-    for kb in SIZES_KB:
-        src, recs_per_pass, code_bytes = kernel(kb)
-        out.write(src)
-        table.append((kb, recs_per_pass, code_bytes))
+    global NO_READS, NO_SMOV, NO_FMA
+    for tag, (NO_READS, NO_SMOV, NO_FMA) in (("", (False, False, False)), ("_noreads", (True, False, False)),
+                                             ("_nosmov", (False, True, False)), ("_fmaonly", (True, True, False)),
+                                             ("_nofma", (False, False, True))):
+        for kb in SIZES_KB:
+            src, recs_per_pass, code_bytes = kernel(kb, tag=tag)
+            out.write(src)
+            table.append(("%d%s" % (kb, tag), recs_per_pass, code_bytes))
     out.write(r"""
-typedef void (*Kern)(float *, int, int);
-struct Var { int kb; Kern fn; double recs; double code; };
+typedef void (*Kern)(float *, int, int, unsigned long long *);
+struct Var { const char *kb; Kern fn; double recs; double code; };
 int main(int argc, char **argv) {
   float *dout; CK(hipMalloc(&dout, 1 << 20));
   Var vars[] = {
 """)
     for (kb, recs, code) in table:
-        out.write("    {%d, k_is%d, %d.0, %d.0},\n" % (kb, kb, recs, code))
+        out.write('    {"%s", k_is%s, %d.0, %d.0},\n' % (kb, kb, recs, code))
     out.write(r"""  };
-  printf("%-10s %-6s %8s %12s %12s %14s\n", "code/WG", "waves", "ms", "pkFMA TF/s", "ns/record", "ifetch GB/s/CU");
+  unsigned long long *dclk; CK(hipMalloc(&dclk, 256 * 16));
+  printf("%-16s %-6s %8s %12s %12s %14s %8s %12s\n", "code/WG KiB", "waves", "ms", "pkFMA TF/s", "ns/record", "ifetch GB/s/CU", "GHz", "cyc/record");
   for (const Var &v : vars) {
     CK(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     for (int own = 0; own < 2; ++own) {
       // about the same number of records per wave in every configuration
       int iters = (int)(4.0e5 / v.recs); if (iters < 2) iters = 2;
-      hipLaunchKernelGGL(v.fn, dim3(256), dim3(512), 65536, 0, dout, 2, own);
+      hipLaunchKernelGGL(v.fn, dim3(256), dim3(512), 65536, 0, dout, 2, own, dclk);
       CK(hipDeviceSynchronize());
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(v.fn, dim3(256), dim3(512), 65536, 0, dout, iters, own);
+      hipLaunchKernelGGL(v.fn, dim3(256), dim3(512), 65536, 0, dout, iters, own, dclk);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
       const double recs = v.recs * iters;                 // per wave
       const double flops = recs * 4 * 128 * 2 * 8 * 256;   // 4 pk_fma x 128 FMA, 8 waves, 256 WGs
       const double code_per_wave = v.code / 8 * iters;
-      printf("%6d KiB %-6s %8.3f %12.1f %12.2f %14.1f\n", v.kb, own ? "own" : "same", ms, flops / (ms * 1e-3) / 1e12,
-             ms * 1e6 / recs, code_per_wave * (own ? 8 : 1) / (ms * 1e-3) / 1e9);
+      unsigned long long hc[512]; CK(hipMemcpy(hc, dclk, sizeof(hc), hipMemcpyDeviceToHost));
+      double cyc = 0, rt = 0; for (int i = 0; i < 256; ++i) { cyc += hc[2 * i]; rt += hc[2 * i + 1]; }
+      printf("%-16s %-6s %8.3f %12.1f %12.2f %14.1f %8.3f %12.1f\n", v.kb, own ? "own" : "same", ms, flops / (ms * 1e-3) / 1e12,
+             ms * 1e6 / recs, code_per_wave * (own ? 8 : 1) / (ms * 1e-3) / 1e9, cyc / (rt * 10.0), cyc / 256 / recs);
     }
   }
   return 0;
