@@ -176,8 +176,21 @@ static int upload(escoin_plan *p, hipStream_t stream) {
   if (want_tiled) {
     if (!tiled_supported(g))
       return fail(ESCOIN_EINVAL, "tiled kernel requested for a geometry it does not support");
-    // AUTO: generated code where it can be had, else the LDS-staged stream
-    const bool try_jit = p->kernel_choice == ESCOIN_KERNEL_JIT || (p->kernel_choice == ESCOIN_KERNEL_AUTO && jit_available());
+    // AUTO: generated code (jit_codegen.h) for layers at least 82 % sparse, the LDS-staged stream
+    // above that density: measured on the ResNet-50 and AlexNet sets at 60-95 % sparsity (same-box
+    // A/B, profiles/r03_jit_vs_stream.md) generated code wins from 85 % on every layer (ResNet step
+    // -15 % at 90 %) and loses up to 15 % on AlexNet's 13 x 13 layers at 80 % and below, where one
+    // scalar move per nonzero is a larger share of the walk.  ESCOIN_JIT_MAX_DENSITY_PCT moves the cut.
+    static const int jit_max_density_pct = getenv("ESCOIN_JIT_MAX_DENSITY_PCT") ? atoi(getenv("ESCOIN_JIT_MAX_DENSITY_PCT")) : 18;
+    double dens_sparse = 0;
+    {
+      long nz = 0, ng = 0;
+      for (int grp = 0; grp < G; ++grp)
+        if (!dense[grp]) { nz += (long)p->colidx[grp].size(); ++ng; }
+      dens_sparse = ng ? (double)nz / (per_group * ng) : 0.0;
+    }
+    const bool try_jit = p->kernel_choice == ESCOIN_KERNEL_JIT ||
+                         (p->kernel_choice == ESCOIN_KERNEL_AUTO && jit_available() && dens_sparse * 100.0 <= jit_max_density_pct);
     int rc = ESCOIN_OK;
     if (try_jit) {
       rc = tiled_build(p, stream, true);

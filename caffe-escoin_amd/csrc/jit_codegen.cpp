@@ -29,6 +29,7 @@ Options options_from_env() {
   if (const char *e = getenv("ESCOIN_JIT_DEPTH")) o.depth = std::max(1, std::min(2, atoi(e)));
   if (const char *e = getenv("ESCOIN_JIT_HOIST")) o.hoist_weight = atoi(e) != 0;
   if (const char *e = getenv("ESCOIN_JIT_PRIO_ROWS")) o.prio_rows = std::max(0, atoi(e));
+  if (const char *e = getenv("ESCOIN_JIT_PRIO_WAVES")) o.prio_waves = std::max(0, atoi(e));
   if (const char *e = getenv("ESCOIN_JIT_ABL")) o.ablate = atoi(e);
   if (const char *e = getenv("ESCOIN_JIT_PREFETCH")) o.prefetch = atoi(e) != 0;
   return o;
@@ -73,7 +74,9 @@ struct Lds {
 // n_pref > 0: the unit starts with n_pref loads over the next unit's code; returns the index (in
 // `c`) of the distance literal to patch (0: none).
 size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const std::vector<Piece> &pieces,
-                 const Options &opt, int n_pref) {
+                 const Options &opt_in, int n_pref, int wave) {
+  Options opt = opt_in;
+  if (opt.prio_waves > 0 && (wave < 0 || wave >= opt.prio_waves)) opt.prio_rows = 0;
   size_t patch = 0;
   if (n_pref > 0) {
     enc_getpc(c, kSPref);                    // s[50:51] = address of the instruction after this one
@@ -239,13 +242,13 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
           live.push_back(std::move(row));
         }
         p.n_rows += (long)live.size();
-        // this wave's pieces of the block staged while this unit runs: block blk + 1, or block 0 of
-        // the workgroup's next tile
+        // this wave's pieces of the block staged while this unit runs: block blk + ahead of this tile
+        // or, past its last block, of the workgroup's next tile
         pieces.clear();
         if (opt.dma.on) {
           const DmaPlan &d = opt.dma;
           const int wave = ocg % d.waves;
-          const int nb = (blk + 1) % t.n_icb;
+          const int nb = (blk + d.ahead) % t.n_icb;
           const int nch = std::min(t.icb, g.Cg - nb * t.icb);
           const long total = (long)nch * d.qpc;
           const int n_instr = (int)((total + 63) / 64);
@@ -264,7 +267,7 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
         while ((p.code.size() * 4) % kUnitAlign) enc_nop(p.code);
         p.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk] = (uint32_t)(p.code.size() * 4);
         const size_t at = p.code.size();
-        patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref));
+        patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref, t.pix_waves == 1 ? ocg % t.oc_waves : -1));
         *max_unit_bytes = std::max(*max_unit_bytes, (p.code.size() - at) * 4);
       }
   // the distances: unit (cg, ocg, blk) touches the code of (cg, ocg, (blk + 1) % n_icb)
@@ -278,6 +281,7 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
     }
   // instruction prefetch and the code touches run past the last unit: keep them inside the blob
   for (int i = 0; i < 64 + n_pref * 1024; ++i) enc_nop(p.code);
+  p.n_pref = n_pref;
   return p;
 }
 

@@ -125,6 +125,8 @@ struct DmaPlan {
   int waves = 8;            // waves sharing the fill (piece i is issued by wave i % waves)
   bool nt = false;          // non-temporal loads (the layer's input is read by one workgroup column)
   int spread_pct = 70;      // the pieces go out over the first this many percent of a unit's rows
+  int ahead = 1;            // the unit of block k stages block k + ahead (plane buffers - 1: 1, or 2 when two
+                            // fills are kept in flight)
 };
 
 // Smallest period lcm(qpc', 64) <= max_period over qpc' in [qpc, qpc * (1 + slack)]: *padded = qpc'
@@ -144,7 +146,10 @@ constexpr int kVPrefDead = 62, kVPrefLane = 63, kSPref = 50;
 struct Options {
   int depth = 2;          // rows read ahead (1 or 2; three input sets allow 2)
   int hoist_weight = 1;   // s_mov of record j+1 issued before the FMAs of record j
-  int prio_rows = 0;      // > 0: s_setprio alternates every this many rows (0: never)
+  int prio_rows = 0;      // > 0: s_setprio alternates 1 / 0 every this many rows (0: never) ...
+  int prio_waves = 0;     // ... in the units of the first this many waves of a workgroup (0: every unit): the
+                          // first-dispatched half loses to a second half that runs at a constant priority 1
+                          // and wins every tie against it at 1 (oldest first), so it alternates
   int ablate = 0;         // timing experiments only (ESCOIN_JIT_ABL; wrong results): 1 no FMAs, 2 no LDS
                           // reads, 4 no weight moves, 8 empty units
   DmaPlan dma;
@@ -157,6 +162,7 @@ struct Program {
   std::vector<uint32_t> unit_off;   // [conv group][n_ocg][n_icb]: byte offset of the unit's entry
   std::vector<uint32_t> chan;       // slot -> output channel, as WeightStream::chan
   long n_rows = 0, n_records = 0, n_dma = 0;
+  int n_pref = 0;                   // code touches (plain loads) at the start of every unit
   bool overflow = false;            // an LDS offset does not fit the instruction's 16-bit field
 };
 

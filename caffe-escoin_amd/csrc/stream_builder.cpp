@@ -112,7 +112,14 @@ double launch_cost_us(const ConvGeom &g, const Tiling &t, int n_cu) {
   const long gx = std::min(tiles, std::max<long>(1, cus / gy));
   const long tiles_per_wg = (tiles + gx - 1) / gx;
   const long waves_of_wgs = (gx * gy + cus - 1) / cus;
-  return (double)tiles_per_wg * per_tile * (double)waves_of_wgs;
+  // ... and no faster than its HBM traffic: every workgroup column stages the whole input once
+  // more.  The first read comes from HBM (~4.5 TB/s through the LDS-DMA path, measured on GoogLeNet's
+  // 28 x 28 layers), the columns' re-reads mostly from the Infinity Cache (counted at half price).
+  // Without this term 160 output channels at 95 % were cut into two passes of 10 channels per wave
+  // (one pass of 20 runs in 2/3 of the time).
+  const double in_bytes = 4.0 * g.N * g.C * g.H * g.W, out_bytes = 4.0 * g.N * g.M * g.OH * g.OW;
+  const double hbm_us = (in_bytes * (1.0 + 0.5 * (t.n_ocblk - 1)) + out_bytes) / 4.5e6;
+  return std::max((double)tiles_per_wg * per_tile * (double)waves_of_wgs, hbm_us);
 }
 
 // The tiling of one concrete (H, W) cut: the cheapest of the candidates (more passes = fewer

@@ -235,6 +235,7 @@ static int run(const Case &cs, bool use_jit) {
       jo.dma.chan_bytes = (uint32_t)(cs.H * cs.W * 4);
       jo.dma.nt = (cs.N & 2) != 0;
       jo.dma.spread_pct = 40 + 10 * (cs.M % 5);
+      jo.dma.ahead = (t.n_icb >= 2 && (cs.C & 1)) ? 2 : 1;      // two fills in flight: the unit of block k stages block k + 2
     }
     jdma = jo.dma;
     jp = jit::build_program(g, t, rp, ci, va, jo);
@@ -355,7 +356,7 @@ static int run(const Case &cs, bool use_jit) {
               pref_of[ui] = pref;
               unit_end[ui] = last_return_pc + 4;
               if (jdma.on) {
-                const int nb = (blk + 1) % t.n_icb;
+                const int nb = (blk + jdma.ahead) % t.n_icb;
                 const int nch = std::min(t.icb, g.Cg - nb * t.icb);
                 const long total = (long)nch * jdma.qpc;
                 const int n_instr = (int)((total + 63) / 64);

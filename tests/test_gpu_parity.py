@@ -41,7 +41,7 @@ def _kernels(pkg, desc=None):
     jit_codegen.h), the LDS-staged stream kernel where the geometry allows, dense MFMA."""
     ks = [pkg.KERNEL_GENERIC, pkg.KERNEL_AUTO, pkg.KERNEL_DENSE]
     if desc is not None and _tiled_ok(desc):
-        ks.insert(2, pkg.KERNEL_TILED)
+        ks[2:2] = [pkg.KERNEL_TILED, pkg.KERNEL_JIT]
     return ks
 
 
@@ -67,7 +67,7 @@ def test_golden_fixtures(pkg, torch_cuda, path):
     # ... and through the tiling (channels per wave, images per tile, blocks) a batch of 256 / 64
     # gets: the weight stream and tile shapes of the benchmarked configurations
     for tb in (256, 64):
-        for kernel in [pkg.KERNEL_AUTO] + ([pkg.KERNEL_TILED] if _tiled_ok(gd.desc(pkg)) else []):
+        for kernel in [pkg.KERNEL_AUTO] + ([pkg.KERNEL_TILED, pkg.KERNEL_JIT] if _tiled_ok(gd.desc(pkg)) else []):
             got, name = _run(pkg, torch_cuda, gd.desc(pkg), gd.w, gd.x, gd.bias, kernel, tiling_batch=tb)
             assert rel_err(got, gd.top) <= TOL, "%s via %s, tiling_batch %d" % (gd.name, name, tb)
 
@@ -570,14 +570,14 @@ def test_randomised_tiled_geometries(pkg, oracle, synth, torch_cuda, seed):
         # a batch of 256 -- the last two give channel groups of 4-24 per wave, several images per
         # tile and second payload quads, i.e. the streams of the benchmarked configurations
         tb = (0, 64, 256)[k % 3]
-        for kernel in (pkg.KERNEL_AUTO, pkg.KERNEL_TILED):      # generated code / LDS-staged stream
-            if kernel == pkg.KERNEL_TILED and not _tiled_ok(pkg.ConvDesc.from_shape(s)):
+        for kernel in (pkg.KERNEL_JIT, pkg.KERNEL_TILED, pkg.KERNEL_AUTO):      # generated code / LDS-staged stream / the plan's own pick
+            if kernel != pkg.KERNEL_AUTO and not _tiled_ok(pkg.ConvDesc.from_shape(s)):
                 continue
             got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel,
                              tiling_batch=tb, dense_threshold_pct=100)
             assert rel_err(got, want) <= TOL, "%s %s tb=%d via %s: %g" % (s.name, (N, C, H, W, M, K, pad, group, sp), tb, name, rel_err(got, want))
             checked += "jit" in name
-    assert checked >= 40      # nearly all of these must have gone down the tiled path
+    assert checked >= 40      # nearly all of these must have gone down the generated-code path at least once
 
 
 def test_batches_beyond_one_buffer_descriptor(pkg, oracle, synth):

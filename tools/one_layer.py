@@ -18,21 +18,30 @@ synth = pkg.synth
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "res5"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    shapes = {s.name.split("_")[0]: s for s in synth.resnet50_3x3(N=256, sparsity=0.9)}
+    sp = float(os.environ.get("ONE_LAYER_SPARSITY", "0")) or None
+    shapes = {s.name.split("_")[0]: s for s in synth.resnet50_3x3(N=256, sparsity=sp or 0.9)}
+    shapes.update({"alex" + str(i + 2): s for i, s in enumerate(synth.alexnet(N=128, sparsity=sp or 0.8))})
+    shapes.update({"goog%d" % i: s for i, s in enumerate(synth.googlenet_1x1(N=256, sparsity=sp or 0.95))})
     s = shapes[which]
-    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    kern = {"auto": pkg.KERNEL_AUTO, "jit": pkg.KERNEL_JIT, "tiled": pkg.KERNEL_TILED}[os.environ.get("ONE_LAYER_KERNEL", "auto")]
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kern)
     plan.weight_align(synth.pruned_weights(s, 1))
     dev = torch.device("cuda:0")
-    x = torch.rand((s.N, s.C, s.H, s.W), device=dev) * 2 - 1
+    # ONE_LAYER_BUFS=k: rotate k input / output pairs (more than the 256 MB Infinity Cache holds: HBM-cold)
+    nb = int(os.environ.get("ONE_LAYER_BUFS", "1"))
+    xs = [torch.rand((s.N, s.C, s.H, s.W), device=dev) * 2 - 1 for _ in range(nb)]
+    ys = [torch.empty((s.N, s.M) + tuple(plan.out_hw), device=dev) for _ in range(nb)]
+    x = xs[0]
+    bias = torch.zeros(s.M, device=dev) if s.bias else None
     for _ in range(20):
-        y = plan.forward(x, None)
+        y = plan.forward(x, bias)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for rep in range(5):
         a.record()
-        for _ in range(n):
-            y = plan.forward(x, None)
+        for i in range(n):
+            y = plan.forward(xs[i % nb], bias, ys[i % nb])
         b.record()
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) / n * 1e3)
