@@ -152,29 +152,6 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
 
 Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu) {
   if (n_cu < 1) n_cu = 256;
-  // Opt-in experiment (ESCOIN_FLAT=1): a pointwise layer (1x1, stride 1, no padding) whose channel
-  // planes are whole quads of pixels does not care where images or rows end -- per channel, the
-  // batch is walked as ONE run of N * H*W pixels cut into rows of 256, a workgroup tile is 512
-  // consecutive pixels of it, so every lane and every staged byte is a real pixel (a 28 x 28 plane
-  // cut into two bands of 16 rows of 32 columns uses 77 % of them).  Measured on GoogLeNet's 1x1
-  // layers at batch 256 (r02): no gain -- the tiles per CU round up to the same number of passes
-  // (392 flat tiles vs 512 banded ones on 256 CUs: two rounds either way), and the 14 x 14 and
-  // 4 x 4 layers get fewer workgroups than CUs -- so it stays off by default.
-  static const bool want_flat = getenv("ESCOIN_FLAT") != nullptr && atoi(getenv("ESCOIN_FLAT")) != 0;
-  if ((want_flat || g.density < 0.f) && g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H && g.OW == g.W &&
-      (g.H * g.W) % 4 == 0) {
-    ConvGeom c = g;
-    const long total = (long)g.N * g.H * g.W;
-    c.N = 1;
-    c.W = c.OW = 256;
-    c.H = c.OH = (int)((total + 255) / 256);
-    Tiling t = tile_for(c, waves_per_wg, lds_budget_bytes, n_cu);
-    if (t.ok && t.band_mode) {
-      t.flat = true;
-      t.chan_hw = g.H * g.W;
-      return t;
-    }
-  }
   Tiling best = tile_for(g, waves_per_wg, lds_budget_bytes, n_cu);
   // A pointwise layer (1x1, no padding) does not care where the rows of an image break: its
   // H*W pixels are one contiguous run per channel.  These layers are bound by the LDS-DMA fill rate

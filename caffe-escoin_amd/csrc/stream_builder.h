@@ -50,9 +50,6 @@ struct Tiling {
   int rows_per_wg = 0;   // pix_waves * 2 * rows_per_slab flattened rows
   int tr = 0;            // output rows per segment
   int nseg = 0;          // segments (whole images) per workgroup; 1 in band mode
-  bool flat = false;     // pointwise layer walked as ONE image of 256-pixel rows over the whole
-                         // batch (H = rows for desc.N images; chan_hw = the real H*W): see choose_tiling
-  int chan_hw = 0;       // flat mode: pixels per channel plane of a real image
   bool band_mode = false;// true: a workgroup covers `tr` rows of ONE image
   int bands = 0;         // bands per image (band mode) else 1
   int plane_rows = 0;    // tr + KH - 1

@@ -24,7 +24,7 @@ static float frand() {
   return ((rng_state >> 8) & 0xFFFF) / 32768.0f - 1.0f;
 }
 
-struct Case { int N, C, H, W, M, KH, KW, ph, pw, group; float sparsity; int waves; int lds; int ncu = 1; bool flat = false; };
+struct Case { int N, C, H, W, M, KH, KW, ph, pw, group; float sparsity; int waves; int lds; int ncu = 1; };
 
 // ---- interpreter of the code jit_codegen.cpp generates (the five instruction forms it emits) ----
 // Registers of one wave: v[lane][256].  LDS reads land only when a counted s_waitcnt retires them
@@ -195,7 +195,7 @@ static int run(const Case &cs, bool use_jit) {
   g.OW = cs.W + 2 * cs.pw - cs.KW + 1;
   g.Cg = cs.C / cs.group;
   g.Mg = cs.M / cs.group;
-  g.density = cs.flat ? -1.0f : 1.0f - cs.sparsity;   // (a negative density asks choose_tiling for the flat pointwise mode)
+  g.density = 1.0f - cs.sparsity;
   // ncu = 1 (default): as on a full chip with a large batch, the fewest passes win; the cases
   // with ncu = 256 see a nearly empty chip and spread the channels over many workgroups
   Tiling t = choose_tiling(g, cs.waves, cs.lds, cs.ncu);
@@ -282,8 +282,7 @@ static int run(const Case &cs, bool use_jit) {
   long dma_checked = 0;
   std::vector<float> got((size_t)g.N * g.M * g.OH * g.OW, -777.f);
   std::vector<int> written(got.size(), 0);
-  const int n_tiles = t.flat ? t.bands : t.band_mode ? g.N * t.bands : (g.N + t.nseg - 1) / t.nseg;
-  const long flat_total = (long)g.N * g.H * g.W;   // flat mode: the batch as one run of pixels per channel
+  const int n_tiles = t.band_mode ? g.N * t.bands : (g.N + t.nseg - 1) / t.nseg;
   std::vector<float> lds((size_t)t.icb * t.plane_ch_floats);
   for (int tile = 0; tile < n_tiles; ++tile)
     for (int cg = 0; cg < g.group; ++cg)
@@ -296,17 +295,6 @@ static int run(const Case &cs, bool use_jit) {
           for (int icl = 0; icl < t.icb; ++icl) {
             const int ic = blk * t.icb + icl;
             if (ic >= g.Cg) continue;
-            if (t.flat) {
-              for (int pr = 0; pr < t.plane_rows; ++pr)
-                for (int xx = 0; xx < 256; ++xx) {
-                  const long pf = ((long)tile * t.tr + pr) * 256 + xx;
-                  if (pf >= flat_total) continue;
-                  const long n = pf / t.chan_hw, rem = pf % t.chan_hw;
-                  lds[(size_t)icl * t.plane_ch_floats + (size_t)pr * t.RS + xx] =
-                      x[((size_t)n * g.C + cg * g.Cg + ic) * t.chan_hw + rem];
-                }
-              continue;
-            }
             for (int seg = 0; seg < t.nseg; ++seg) {
               int n, y0;
               if (t.band_mode) { n = tile / t.bands; y0 = (tile % t.bands) * t.tr; }
@@ -457,18 +445,6 @@ static int run(const Case &cs, bool use_jit) {
                 int n, y;
                 if (t.band_mode) { n = tile / t.bands; y = (tile % t.bands) * t.tr + yl; }
                 else { n = tile * t.nseg + seg; y = yl; }
-                if (t.flat) {
-                  for (int e = 0; e < 4; ++e) {
-                    const long pf = (long)y * 256 + 4 * j + e;
-                    if (pf >= flat_total) continue;
-                    const long nn = pf / t.chan_hw, rem = pf % t.chan_hw;
-                    const float sum = acc[((size_t)wave * 64 + lane) * kAccAll + tl * kAccRegsPerTile + 4 * gl + e] + bias[oc];
-                    const size_t o = ((size_t)nn * g.M + oc) * t.chan_hw + rem;
-                    got[o] = sum;
-                    written[o]++;
-                  }
-                  continue;
-                }
                 if (n >= g.N || y >= t.OH) continue;
                 for (int e = 0; e < 4; ++e) {
                   const int xo = 4 * j + e;
@@ -546,14 +522,11 @@ int main() {
       {5, 30, 7, 7, 48, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 256},    // empty chip, pointwise
       {40, 16, 7, 7, 64, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 8},     // 8 CUs: images per workgroup vs passes
       {1, 48, 56, 56, 64, 1, 1, 0, 0, 1, 0.97f, 8, 65536, 256}, // one channel per wave, units of 0-2 rows: the code's own plane DMA goes out in the tail
-      {9, 12, 28, 28, 20, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 1, true},       // pointwise, H*W % 4 == 0: flat mode
-      {5, 10, 14, 14, 40, 1, 1, 0, 0, 2, 0.8f, 8, 65536, 1, true},       // flat mode, groups, images straddling rows
-      {3, 6, 4, 4, 12, 1, 1, 0, 0, 1, 0.5f, 8, 65536, 1, true},          // flat mode asked for, batch smaller than one tile
   };
   int bad = 0;
   for (const Case &c : cases) {
     bad += run(c, false) != 0;
-    if (!c.flat) bad += run(c, true) != 0;     // the same geometry through the generated code
+    bad += run(c, true) != 0;     // the same geometry through the generated code
   }
   printf(bad ? "FAILED %d case(s)\n" : "all cases OK\n", bad);
   return bad ? 1 : 0;

@@ -80,37 +80,26 @@ def test_persisted_csr_feeds_the_hip_path(tmp_path, pkg, oracle, synth):
         plan.close()
 
 
-def test_flat_pointwise_cut_is_bit_compatible(pkg, oracle, synth):
-    """ESCOIN_FLAT=1 (opt-in: pointwise layers walked as one run of pixels per channel over the whole
-    batch) gives the oracle's numbers on a layer whose images straddle the 256-pixel rows and on a
-    batch that ends inside a tile; child process, because the tiling choice reads the variable once."""
-    code = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-import __graft_entry__ as ge
-pkg = ge.load_package(); oracle = ge.load_oracle(); synth = pkg.synth
-dev = torch.device("cuda:0")
-worst = 0.0
-for k, s in enumerate([synth.shape("f28", 37, 24, 28, 28, 40, 1, sparsity=0.9),
-                       synth.shape("f14", 150, 40, 14, 14, 96, 1, sparsity=0.95, group=2),
-                       synth.shape("f56", 9, 16, 56, 56, 16, 1, sparsity=0.8, bias=False)]):
-    w, b, x = synth.pruned_weights(s, 70 + k), synth.bias_vector(s, 80 + k), synth.activations(s, 90 + k)
-    plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_TILED)
-    plan.weight_align(w)
-    top = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev) if b is not None else None).cpu().numpy()
-    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
-    want = oracle.conv_forward(g, x, w, b, gate=False, threads=4)
-    worst = max(worst, float(np.abs(top - want).max() / max(1e-6, np.abs(want).max())))
-    # partial batch: ends inside a 512-pixel tile
-    part = plan.forward(torch.from_numpy(x[:5]).to(dev), torch.from_numpy(b).to(dev) if b is not None else None).cpu().numpy()
-    worst = max(worst, float(np.abs(part - want[:5]).max() / max(1e-6, np.abs(want).max())))
-print("REL_ERR %%g" %% worst)
-sys.exit(0 if worst <= 1e-4 else 1)
-""" % ROOT
-    env = dict(os.environ, ESCOIN_FLAT="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    assert out.returncode == 0, out.stdout.decode()
-    assert "REL_ERR" in out.stdout.decode()
+def test_pointwise_batches_that_end_inside_a_tile(pkg, oracle, synth):
+    """Pointwise layers whose images do not fill their last tile, and partial batches that end inside
+    one (ragged N * H * W): both LDS-tiled kernel families against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    for k, s in enumerate([synth.shape("f28", 37, 24, 28, 28, 40, 1, sparsity=0.9),
+                           synth.shape("f14", 150, 40, 14, 14, 96, 1, sparsity=0.95, group=2),
+                           synth.shape("f56", 9, 16, 56, 56, 16, 1, sparsity=0.8, bias=False)]):
+        w, b, x = synth.pruned_weights(s, 70 + k), synth.bias_vector(s, 80 + k), synth.activations(s, 90 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
+        want = oracle.conv_forward(g, x, w, b, gate=False, threads=4)
+        for kernel in (pkg.KERNEL_TILED, pkg.KERNEL_JIT):
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel)
+            plan.weight_align(w)
+            bias = torch.from_numpy(b).to(dev) if b is not None else None
+            top = plan.forward(torch.from_numpy(x).to(dev), bias).cpu().numpy()
+            assert rel_err(top, want) <= 1e-4, (s.name, plan.kernel_name)
+            part = plan.forward(torch.from_numpy(x[:5]).to(dev), bias).cpu().numpy()
+            assert rel_err(part, want[:5]) <= 1e-4, (s.name, plan.kernel_name)
+            plan.close()
 
 
 def test_forward_is_capturable_in_a_hip_graph(pkg, oracle, synth):

@@ -94,6 +94,7 @@ def run_chain(args, pkg, synth):
     print("[cxh] GPU device name: %s" % torch.cuda.get_device_name(0))
     plans, weights = [], []
     t0 = time.perf_counter()
+    align_ms = []
     for i, (name, kind, s, relu, role) in enumerate(chain):
         w = synth.pruned_weights(s, 1000 + 31 * i)
         # keep the activations O(1) through 16 blocks: He-style scale for the surviving weights
@@ -101,11 +102,15 @@ def run_chain(args, pkg, synth):
         plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), conv_mode=args.conv_mode)
         if args.dense_gate:
             plan.set_option("dense_gate", 1)
+        ta = time.perf_counter()
         plan.weight_align(w)
+        align_ms.append(1e3 * (time.perf_counter() - ta))
         plans.append(plan)
         weights.append(w)
     torch.cuda.synchronize()
-    print("[cxh] WeightAlign of %d layers: %.1f ms" % (len(chain), 1e3 * (time.perf_counter() - t0)))
+    print("[cxh] WeightAlign of %d layers: %.1f ms (one-time, per weight load: net.cpp:819; slowest: %s)" %
+          (len(chain), 1e3 * (time.perf_counter() - t0),
+           ", ".join("%s %.0f ms" % (chain[i][0], align_ms[i]) for i in sorted(range(len(chain)), key=lambda i: -align_ms[i])[:3])))
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     x0 = torch.rand((batch, 64, 56, 56), device=dev, generator=g) * 2 - 1
@@ -234,12 +239,15 @@ def main():
 
     plans, bottoms, tops, biases = [], {}, {}, []
     t0 = time.perf_counter()
+    align_ms = []
     for name, s in layers:
         plan = pkg.Plan(pkg.ConvDesc.from_shape(s), conv_mode=args.conv_mode)
         if args.dense_gate:
             plan.set_option("dense_gate", 1)
         w, b = weights[name]
+        ta = time.perf_counter()
         plan.weight_align(w)
+        align_ms.append(1e3 * (time.perf_counter() - ta))
         plans.append(plan)
         biases.append(torch.from_numpy(b).to(dev) if b is not None else None)
         key = (s.C, s.H, s.W, s.M, s.KH, s.stride_h, s.pad_h)
@@ -273,12 +281,12 @@ def main():
         print("[cxh] Total CONV time: %.2f ms" % ms.sum())
     print("[cxh] Average CONV time: %.3f ms over %d iterations (batch %d)" %
           (conv_total / args.iterations, args.iterations, layers[0][1].N))
-    print("%-26s %-34s %9s %9s %8s" % ("layer", "kernel", "us", "TFLOP/s", "GB/s"))
+    print("%-26s %-34s %9s %9s %8s %14s" % ("layer", "kernel", "us", "TFLOP/s", "GB/s", "WeightAlign ms"))
     for li, (name, s) in enumerate(layers):
         us = 1e3 * per_layer[li] / args.iterations
-        print("%-26s %-34s %9.1f %9.2f %8.0f" % (name, plans[li].kernel_name[:34], us,
-                                                 synth.flops(s) / us * 1e-6,
-                                                 synth.algorithmic_bytes(s) / us * 1e-3))
+        print("%-26s %-34s %9.1f %9.2f %8.0f %14.1f" % (name, plans[li].kernel_name[:34], us,
+                                                        synth.flops(s) / us * 1e-6,
+                                                        synth.algorithmic_bytes(s) / us * 1e-3, align_ms[li]))
 
     if args.check:
         oracle = ge.load_oracle()
