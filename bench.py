@@ -341,6 +341,16 @@ def cpu_baseline(oracle, synth, shapes, budget_s):
     return out
 
 
+def traffic_per_layer(workload):
+    """{layer name: HBM bytes per launch} from the committed PMC summary (tools/save_profile.py breaks the
+    counters down by dispatch order), or {}."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    try:
+        return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(path)).get("_per_layer", {}).items()}
+    except Exception:
+        return {}
+
+
 def traffic_with_provenance(workload, kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (FETCH_SIZE x 2
     + WRITE_SIZE, MI355X_MICROARCH.md); collected in a separate rocprofv3 --pmc run
@@ -469,6 +479,7 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         i["ms"] += m
         i["launches"] += 1
     per_layer, seen = [], {}
+    layer_traffic = traffic_per_layer(args.workload)
     for li, (s, plan, bias, si, lid) in enumerate(layers):
         seen.setdefault(si, []).append(layer_ms[li])
     for si, s in enumerate(shapes):
@@ -479,7 +490,11 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         per_layer.append({"layer": s.name, "count": s.count, "us": round(m * 1e3, 1),
                           "alg_GBps": round(byt / m / 1e6, 1), "sparse_TFLOPs": round(flo / m / 1e9, 2),
                           "hbm_frac": round(t_hbm / (m * 1e-3), 4), "fma_frac": round(t_fma / (m * 1e-3), 4),
-                          "binding_frac": round(max(t_hbm, t_fma) / (m * 1e-3), 4)})
+                          "binding_frac": round(max(t_hbm, t_fma) / (m * 1e-3), 4),
+                          "alg_bytes": int(byt),
+                          # PMC (separate run, profiles/traffic_<workload>.json): HBM bytes of this layer's launch
+                          "hbm_traffic": layer_traffic.get(s.name),
+                          "traffic_over_alg": round(layer_traffic[s.name] / byt, 3) if s.name in layer_traffic else None})
         log("  gpu %-16s %-44s %8.1f us  %7.1f GB/s alg  %6.2f TFLOP/s  binding %.3f  x%d" %
             (s.name, name, m * 1e3, byt / m / 1e6, flo / m / 1e9, per_layer[-1]["binding_frac"], s.count))
     dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"])

@@ -3,7 +3,12 @@
 files under profiles/: the rocprofv3 --stats table with kernel names shortened, and the per-kernel
 PMC sums (FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them, per launch).
 
-    python tools/save_profile.py gpurun_out/prof_r01_resnet50 r01_resnet50
+    python tools/save_profile.py gpurun_out/prof_r01_resnet50 r01_resnet50 [bench.json]
+
+With the bench line of the same workload (its roofline.per_layer: layer shapes in launch order and how
+often each repeats) the traffic is also broken down per LAYER SHAPE from the dispatch order -- every
+3x3 layer of the ResNet set runs under one kernel name, and res2's band-halo re-read should be visible
+on its own.
 """
 import csv
 import glob
@@ -54,6 +59,34 @@ def main():
         summary[k] = {c: {"sum": v[0], "launches": v[1], "per_launch": v[0] / max(1, v[1])} for c, v in cs.items()}
     with open("profiles/%s_pmc.json" % tag, "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
+    # ---- per layer shape, from the dispatch order: the escoin launches of a step come in the order of
+    # the bench line's per_layer list (each entry `count` times)
+    per_layer = None
+    if len(sys.argv) > 3:
+        try:
+            bl = json.load(open(sys.argv[3]))["roofline"]["per_layer"]
+            order = []
+            for l in bl:
+                order += [l["layer"]] * int(l["count"])
+            per_layer = {}
+            for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+                for fn in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
+                    rows = [r for r in csv.DictReader(open(fn)) if r["Counter_Name"] == cname and short(r["Kernel_Name"]).startswith("escoin")
+                            and "locator" not in r["Kernel_Name"]]
+                    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+                    if len(rows) % len(order):
+                        print("per-layer breakdown skipped: %d escoin dispatches are not whole steps of %d" % (len(rows), len(order)))
+                        per_layer = None
+                        break
+                    for i, r in enumerate(rows):
+                        d = per_layer.setdefault(order[i % len(order)], {}).setdefault(cname, [0.0, 0, short(r["Kernel_Name"])])
+                        d[0] += float(r["Counter_Value"])
+                        d[1] += 1
+                if per_layer is None:
+                    break
+        except Exception as e:      # noqa: BLE001 (a profile without the breakdown is still a profile)
+            print("per-layer breakdown skipped:", e)
+            per_layer = None
     # bench.py's roofline.traffic: HBM bytes per launch of each escoin kernel.  FETCH_SIZE and
     # WRITE_SIZE are reported in KiB; per MI355X_MICROARCH.md gfx950 counts half the bytes of
     # 16 B/lane streaming reads (buffer_load ... lds included), so fetches are doubled.
@@ -73,6 +106,12 @@ def main():
         except Exception:
             traffic["_commit"] = None
         traffic["_saved"] = time.strftime("%Y-%m-%d %H:%M:%S")
+        if per_layer:
+            traffic["_per_layer"] = {
+                name: {"kernel": cs["FETCH_SIZE"][2],
+                       "hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"][0] / cs["FETCH_SIZE"][1] + cs["WRITE_SIZE"][0] / cs["WRITE_SIZE"][1]) * 1024),
+                       "fetch_kib": cs["FETCH_SIZE"][0] / cs["FETCH_SIZE"][1], "write_kib": cs["WRITE_SIZE"][0] / cs["WRITE_SIZE"][1]}
+                for name, cs in per_layer.items() if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs}
         traffic["_note"] = ("HBM bytes per launch of the dominant kernel, averaged over the launches of "
                             "the bench steps: (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 "
                             "--pmc passes (tools/profile.sh, profiles/%s_pmc.json); FETCH_SIZE doubled "
