@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <vector>
 
 #include "escoin_plan.h"
@@ -51,6 +52,7 @@ struct DenseArgs {
   int Cg, Mg, K, lda, P, relu;
   int n_ptiles, n_mtiles, n_groups;        // tiles: pixel x channel x conv group (of this launch)
   unsigned in_bytes, w_bytes;              // buffer descriptor ranges
+  int vec_out;                             // OH*OW % 4 == 0 and top 16-byte aligned: 16-byte stores through LDS
   unsigned long long group_mask;           // conv groups this launch covers (all ones: every group)
 };
 
@@ -90,8 +92,11 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
   constexpr int NB = WN / 32;                // 32-column MFMA blocks per wave
   constexpr int A_DMA = BM / 8 / 4;          // 1 KiB A pieces per wave and k-step: 4 or 2
   constexpr unsigned kOOB = 0xFFFFFFF0u;
-  __shared__ __attribute__((aligned(1024))) float sA[2][BM * kBK];
-  __shared__ __attribute__((aligned(1024))) float sB[2][kBK * kBN];
+  // one array per buffer: A tile then B tile (the epilogue reuses a whole buffer as its staging area)
+  constexpr int kBufFloats = BM * kBK + kBK * kBN;
+  __shared__ __attribute__((aligned(1024))) float sAB[2][kBufFloats];
+  auto sA = [&](int b) -> float * { return &sAB[b][0]; };
+  auto sB = [&](int b) -> float * { return &sAB[b][BM * kBK]; };
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +107,8 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
   const int nk = (a.K + kBK - 1) / kBK;
   const long n_tiles = (long)a.n_ptiles * a.n_mtiles * a.n_groups;
   const u32x4d rA = make_rsrc(a.w, a.w_bytes), rB = make_rsrc(a.in, a.in_bytes);
-  const unsigned ldsA = (unsigned)(size_t)(&sA[0][0]), ldsB = (unsigned)(size_t)(&sB[0][0]);
+  const unsigned ldsA = (unsigned)(size_t)(&sAB[0][0]), ldsB = (unsigned)(size_t)(&sAB[0][BM * kBK]);
+  constexpr unsigned kBufBytes = (unsigned)kBufFloats * 4u;
 
   // ---- A pieces of this wave: piece i = wave + 4 q covers rows 8 i .. 8 i + 7, lane l -> row
   // 8 i + l / 8, LDS slot l % 8, which holds chunk (l % 8) ^ ((row >> 1) & 7): the same for every q
@@ -149,7 +155,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
 #pragma unroll
     for (int q = 0; q < A_DMA; ++q) {
       const int i = wave + 4 * q;
-      dma16(rA, ldsA + (unsigned)(buf * BM * kBK * 4 + i * 1024), voffA, sa + (unsigned)(i * 8 * a.lda * 4));
+      dma16(rA, ldsA + (unsigned)buf * kBufBytes + (unsigned)(i * 1024), voffA, sa + (unsigned)(i * 8 * a.lda * 4));
     }
     if (POINTWISE4) {
 #pragma unroll
@@ -160,7 +166,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         // 0 * NaN = NaN), so they are staged as zeros like the gathered path's 0x7FFF taps -- the
         // range check sees the VGPR offset only, hence the marker goes there
         const unsigned vo = (k0 + 2 * i + (lane >> 5) < a.K) ? fb_pix[0] : kOOB;
-        dma16(rB, ldsB + (unsigned)(buf * kBK * kBN * 4 + i * 1024), vo, (unsigned)((size_t)(k0 + 2 * i) * hw * 4));
+        dma16(rB, ldsB + (unsigned)buf * kBufBytes + (unsigned)(i * 1024), vo, (unsigned)((size_t)(k0 + 2 * i) * hw * 4));
       }
     } else {
       // this wave's 8 rows of the k-step: their taps are 64 contiguous bytes at a wave-uniform address
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         for (int half = 0; half < 2; ++half) {
           const int ih = fb_ih0[half] + (tdyx & 0xFFFF), iw = fb_iw0[half] + (tdyx >> 16);
           const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-          dma4(rB, ldsB + (unsigned)(buf * kBK * kBN * 4 + (8 * wave + kk) * 512 + half * 256),
+          dma4(rB, ldsB + (unsigned)buf * kBufBytes + (unsigned)((8 * wave + kk) * 512 + half * 256),
                ok ? fb_pix[half] + (unsigned)(toff * 4) : kOOB);
         }
       }
@@ -217,12 +223,12 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
       float4 fa[2][2];
       float fb[2][4][NB];
       auto read_frags = [&](int kg, int s) {
-        fa[s][0] = *reinterpret_cast<const float4 *>(&sA[buf][a_swizzle(ra, 2 * kg + lh)]);
-        fa[s][1] = *reinterpret_cast<const float4 *>(&sA[buf][a_swizzle(ra + 32, 2 * kg + lh)]);
+        fa[s][0] = *reinterpret_cast<const float4 *>(&sA(buf)[a_swizzle(ra, 2 * kg + lh)]);
+        fa[s][1] = *reinterpret_cast<const float4 *>(&sA(buf)[a_swizzle(ra + 32, 2 * kg + lh)]);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int j = 0; j < NB; ++j) fb[s][t][j] = sB[buf][(8 * kg + 4 * lh + t) * kBN + wn * WN + 32 * j + li];
+          for (int j = 0; j < NB; ++j) fb[s][t][j] = sB(buf)[(8 * kg + 4 * lh + t) * kBN + wn * WN + 32 * j + li];
       };
       read_frags(0, 0);
 #pragma unroll
@@ -263,6 +269,48 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) asm volatile("" : "+v"(bv[i][reg]));
+    if (a.vec_out) {
+      // Output rows of whole pixel quads (OH*OW % 4 == 0): transpose through LDS and store 16 bytes
+      // per lane -- a lane of the MFMA's C layout holds ONE pixel of 16 channels, i.e. 4-byte stores
+      // of 256 bytes per instruction, and a layer with few input channels (K = 64: two k-steps per
+      // tile) then spends more time issuing stores than multiplying.  Staging area: the buffer the
+      // tile's last k-step was read from (the other one is being filled for the next tile); a barrier
+      // says everybody is done reading it, the barrier at the next k-step's top that everybody is
+      // done with the staging.  A wave transposes its own 32 x WN half-tiles: no cross-wave traffic.
+      __syncthreads();
+      float *stage = &sAB[buf ^ 1][wave * 32 * WN];
+      constexpr int kQPR = WN / 4;                     // quads per staged row
+      constexpr int kRowsPerIt = 64 / kQPR;            // rows one 64-lane read covers
+      const int c4 = lane % kQPR, r0 = lane / kQPR;
+      const int pq = p0 + wn * WN + 4 * c4;
+      const int nq = pq / ohw, rq = pq - nq * ohw;
+      float *oq = a.out + ((size_t)nq * a.M + (size_t)cg * a.Mg) * ohw + rq;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            float v = acc[i][j][reg] + bv[i][reg];
+            if (a.relu) v = fmaxf(v, 0.f);
+            stage[row * WN + 32 * j + li] = v;
+          }
+        }
+        // (the wave reads back what it wrote itself: LDS operations of a wave complete in order; the
+        // compiler must keep the order too)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 32 / kRowsPerIt; ++it) {
+          const int row = it * kRowsPerIt + r0;
+          const float4 v = *reinterpret_cast<const float4 *>(&stage[row * WN + 4 * c4]);
+          const int m = m0 + wm * 64 + 32 * i + row;
+          if (m < a.Mg && pq < a.P) *reinterpret_cast<float4 *>(oq + (size_t)m * ohw) = v;
+        }
+        asm volatile("" ::: "memory");
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int pj = p0 + wn * WN + 32 * j + li;
@@ -360,6 +408,10 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   const bool pointwise = g.d.KH == 1 && g.d.KW == 1 && g.d.stride_h == 1 && g.d.stride_w == 1 &&
                          g.d.pad_h == 0 && g.d.pad_w == 0;
   const bool vec_b = pointwise && (g.d.H * g.d.W) % 4 == 0 && (reinterpret_cast<uintptr_t>(bottom) & 15) == 0 && P >= 4;
+  {
+    static const bool vo = !(getenv("ESCOIN_DENSE_VEC_OUT") && atoi(getenv("ESCOIN_DENSE_VEC_OUT")) == 0);
+    a.vec_out = vo && (g.OH * g.OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(top) & 15) == 0;
+  }
   a.group_mask = p->use_dense ? ~0ull : p->dense_mask;
   const int bm = g.Mg <= 64 ? 64 : 128;
   a.n_ptiles = (int)((P + kBN - 1) / kBN);

@@ -101,7 +101,10 @@ double launch_cost_us(const ConvGeom &g, const Tiling &t, int n_cu) {
   const double rows = (double)g.Cg * g.KH;
   const double nonempty = 1.0 - std::pow(1.0 - d, (double)t.G * g.KW);
   const double walk = rows * nonempty * 0.060 + rows * g.KW * t.G * d * 0.018;
-  const double dma = (double)g.Cg * t.plane_ch_floats * 4.0 / 50e3;
+  // (planes land at 18-20 GB/s per CU with every CU staging: GoogLeNet's 28 x 28 layers read 154 MB in
+  // 34.6 us with the walk and the stores switched off; rounds 1-2 assumed 50)
+  static const double dma_bytes_per_us = (getenv("ESCOIN_DMA_GBPS") ? atof(getenv("ESCOIN_DMA_GBPS")) : 19.0) * 1e3;
+  const double dma = (double)g.Cg * t.plane_ch_floats * 4.0 / dma_bytes_per_us;
   const double epilogue = 0.15 * t.G * kTilesPerLane;
   const double per_tile = t.n_icb * 1.2 + std::max(walk, dma) + epilogue;
   const long tiles = t.band_mode ? (long)g.N * t.bands : ((long)g.N + t.nseg - 1) / t.nseg;

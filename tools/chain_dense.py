@@ -14,6 +14,7 @@ import caffe_test
 
 pkg = ge.load_package(); synth = pkg.synth
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None      # e.g. "64x56x256,256x56x64": C x H x M filters
 chain = caffe_test.resnet50_chain(synth, batch, 0.9)
 dev = torch.device("cuda:0")
 seen, tot_us, tot_fl = {}, 0.0, 0.0
@@ -21,6 +22,8 @@ for (name, kind, s, relu, role) in chain:
     if kind != "dense":
         continue
     key = (s.C, s.H, s.M, s.stride_h)
+    if only and "%dx%dx%d" % (s.C, s.H, s.M) not in only:
+        continue
     if key not in seen:
         w = synth.pruned_weights(s, 5)
         plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=pkg.KERNEL_DENSE)
