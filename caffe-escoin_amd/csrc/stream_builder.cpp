@@ -77,6 +77,12 @@ Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int 
     const int q = t.plane_ch_floats / 4;
     if (q < p2 && q * 16 >= p2 * 15) t.plane_ch_floats = p2 * 4;
   }
+  // A pointwise image walked as ONE row by a workgroup of its own (14 x 14 as 1 x 196: 49 quads on a
+  // 64-quad row) needs no row pitch: the planes are packed to the quads that exist.  Lanes past the row
+  // read the next channel's quads (theirs are results nobody stores); the fill moves 23 % fewer bytes.
+  if (g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && !t.band_mode && t.nseg == 1 && t.tr == 1 &&
+      !(getenv("ESCOIN_PACK_ROW") && atoi(getenv("ESCOIN_PACK_ROW")) == 0))
+    t.plane_ch_floats = std::min(t.plane_ch_floats, (g.W + 7) / 8 * 8);   // (whole 32 bytes: the stream's row offsets)
   const int per_ch = t.plane_ch_floats * 4;
   // (row offsets travel as offset / 32 in 11-bit fields of the stream: 64 KiB per plane buffer)
   lds_budget_bytes = std::min(lds_budget_bytes, 64 * 1024);
@@ -167,7 +173,7 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, 
   if (g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H && g.OW == g.W) {
     const int hw = g.H * g.W;
     auto slots = [](const Tiling &t) {   // 16-byte LDS slots staged per image and channel
-      return t.band_mode ? (long)t.bands * t.plane_rows * t.S4 : (long)t.plane_rows * t.S4;
+      return t.band_mode ? (long)t.bands * t.plane_rows * t.S4 : (long)t.plane_ch_floats / 4 / t.nseg;
     };
     auto copies = [](const Tiling &t) { return (long)t.H * ((t.W + 3) / 4); };
     auto lane_use = [](const Tiling &t) {
