@@ -54,6 +54,7 @@ struct DenseArgs {
   unsigned in_bytes, w_bytes;              // buffer descriptor ranges
   int vec_out;                             // OH*OW % 4 == 0 and top 16-byte aligned: 16-byte stores through LDS
   unsigned long long group_mask;           // conv groups this launch covers (all ones: every group)
+  int abl;                                 // ESCOIN_ABLATIONS builds: timing experiments (wrong results)
 };
 
 __device__ __forceinline__ int a_swizzle(int row, int chunk) { return row * kBK + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -207,8 +208,14 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x16{0};
     for (int ks = 0; ks < nk; ++ks, buf ^= 1) {
       // this wave's pieces of the step have landed (and the stores of the last epilogue are out) ...
+#ifdef ESCOIN_ABLATIONS
+      if (!(a.abl & 1))     // ESCOIN_DENSE_ABL: 1 no wait for the operands, 2 no operand traffic, 4 no MFMAs
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();   // ... everyone's have, and everyone is done with the other buffer
+#ifdef ESCOIN_ABLATIONS
+      if (!(a.abl & 2))
+#endif
       if (f_tile < n_tiles) {
         fetch(f_k, buf ^ 1);
         if (++f_k == nk) {
@@ -238,6 +245,9 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         // keep the order: next group's LDS reads first, then this group's MFMAs (left alone, the
         // scheduler sinks each read to just above its use and every 4 MFMAs wait for LDS)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef ESCOIN_ABLATIONS
+        if (a.abl & 4) continue;
+#endif
         const float a0[4] = {fa[s][0].x, fa[s][0].y, fa[s][0].z, fa[s][0].w};
         const float a1[4] = {fa[s][1].x, fa[s][1].y, fa[s][1].z, fa[s][1].w};
 #pragma unroll
@@ -413,6 +423,10 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
     a.vec_out = vo && (g.OH * g.OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(top) & 15) == 0;
   }
   a.group_mask = p->use_dense ? ~0ull : p->dense_mask;
+  a.abl = 0;
+#ifdef ESCOIN_ABLATIONS
+  if (const char *e = getenv("ESCOIN_DENSE_ABL")) a.abl = atoi(e);
+#endif
   const int bm = g.Mg <= 64 ? 64 : 128;
   a.n_ptiles = (int)((P + kBN - 1) / kBN);
   a.n_mtiles = (g.Mg + bm - 1) / bm;

@@ -32,6 +32,7 @@ Options options_from_env() {
   if (const char *e = getenv("ESCOIN_JIT_PRIO_WAVES")) o.prio_waves = std::max(0, atoi(e));
   if (const char *e = getenv("ESCOIN_JIT_ABL")) o.ablate = atoi(e);
   if (const char *e = getenv("ESCOIN_JIT_PREFETCH")) o.prefetch = atoi(e) != 0;
+  if (const char *e = getenv("ESCOIN_JIT_ONE_TILE")) o.one_tile = atoi(e) != 0 ? 0 : -1;
   return o;
 }
 
@@ -100,6 +101,7 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     const int base = kVIn0 + 8 * (k % kInSets);
     enc_ds_read_b128(c, base, kVAddrA, rows[k].lds_off);
     lds.issue();
+    if (opt.one_tile) { row_id[k] = lds.issued - 1; return; }
     enc_ds_read_b128(c, base + 4, kVAddrB, rows[k].lds_off);
     row_id[k] = lds.issue();
   };
@@ -178,6 +180,7 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
       const int a = 4 * flat[j]->idx;
       enc_pk_fma(c, kAccA + a, sreg(j), xa);
       enc_pk_fma(c, kAccA + a + 2, sreg(j), xa + 2);
+      if (opt.one_tile) continue;
       enc_pk_fma(c, kAccB + a, sreg(j), xb);
       enc_pk_fma(c, kAccB + a + 2, sreg(j), xb + 2);
     }
@@ -287,7 +290,13 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
 
 Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,
                       const std::vector<std::vector<int>> &colidx,
-                      const std::vector<std::vector<float>> &values, const Options &opt) {
+                      const std::vector<std::vector<float>> &values, const Options &opt_in) {
+  Options opt = opt_in;
+  // Tile B (the lane's second quad: flattened rows rows_per_slab .. 2 rows_per_slab - 1) lies past the
+  // workgroup's last row when all of them fit tile A -- every small pointwise image walked one (or a
+  // few) to a workgroup: no reads, no FMAs for it (the kernel's epilogue stores none of its lanes)
+  if (t.pix_waves == 1 && t.tr * t.nseg <= t.rows_per_slab && opt.one_tile >= 0) opt.one_tile = 1;
+  else opt.one_tile = 0;
   size_t max_unit = 0;
   Program p = build_pass(g, t, rowptr, colidx, values, opt, 0, &max_unit);
   if (!opt.prefetch || p.overflow) return p;

@@ -154,6 +154,8 @@ struct Options {
                           // reads, 4 no weight moves, 8 empty units
   DmaPlan dma;
   int prefetch = 1;       // touch the next unit's code (above)
+  int one_tile = 0;       // set by build_program: the tiling leaves tile B without rows, its reads and FMAs
+                          // are not generated (-1: never, ESCOIN_JIT_ONE_TILE=0)
 };
 Options options_from_env();
 
