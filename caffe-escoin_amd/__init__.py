@@ -29,7 +29,7 @@ API_SYMBOLS = [
     "escoin_last_error", "escoin_device_count", "escoin_out_shape", "escoin_padded_len",
     "escoin_plan_create", "escoin_plan_destroy", "escoin_plan_set_option",
     "escoin_weight_align", "escoin_plan_set_csr", "escoin_plan_nnz", "escoin_plan_get_csr",
-    "escoin_plan_workspace_bytes", "escoin_plan_kernel_name", "escoin_forward",
+    "escoin_plan_workspace_bytes", "escoin_plan_kernel_name", "escoin_plan_tiling_info", "escoin_forward",
     "escoin_gpu_sconv", "escoin_gpu_stretch", "escoin_copy_input_data",
     "escoin_gpu_sparse_dense2csr", "escoin_gpu_sparse_csrmm",
 ]
@@ -100,6 +100,8 @@ def lib():
     L.escoin_plan_workspace_bytes.argtypes = [vp]
     L.escoin_plan_kernel_name.restype = cp
     L.escoin_plan_kernel_name.argtypes = [vp]
+    L.escoin_plan_tiling_info.restype = cp
+    L.escoin_plan_tiling_info.argtypes = [vp]
     L.escoin_forward.restype = ip
     L.escoin_forward.argtypes = [vp, vp, vp, vp, ip, vp]
     L.escoin_gpu_sconv.restype = ip
@@ -209,6 +211,11 @@ class Plan(object):
     @property
     def kernel_name(self):
         return lib().escoin_plan_kernel_name(self._h).decode()
+
+    @property
+    def tiling_info(self):
+        """How the fast kernel tiles the layer (one line; "" for the generic / dense / lowered kernels)."""
+        return lib().escoin_plan_tiling_info(self._h).decode()
 
     def forward_ptr(self, bottom_ptr, bias_ptr, top_ptr, n_images, stream=None):
         """Raw-pointer Forward_gpu (device pointers as ints)."""

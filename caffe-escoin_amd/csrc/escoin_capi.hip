@@ -419,6 +419,10 @@ const char *escoin_plan_kernel_name(const escoin_plan *p) {
   return p ? p->kernel_name.c_str() : "";
 }
 
+const char *escoin_plan_tiling_info(const escoin_plan *p) {
+  return (p && p->aligned && p->tiled.enabled) ? p->tiled.info.c_str() : "";
+}
+
 int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_dev, float *top_dev,
                    int n_images, void *stream) {
   if (!p || !bottom_dev || !top_dev) return fail(ESCOIN_EINVAL, "null argument");

@@ -295,7 +295,9 @@ Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std:
   // Tile B (the lane's second quad: flattened rows rows_per_slab .. 2 rows_per_slab - 1) lies past the
   // workgroup's last row when all of them fit tile A -- every small pointwise image walked one (or a
   // few) to a workgroup: no reads, no FMAs for it (the kernel's epilogue stores none of its lanes)
-  if (t.pix_waves == 1 && t.tr * t.nseg <= t.rows_per_slab && opt.one_tile >= 0) opt.one_tile = 1;
+  // ... and a tiling with one quad per lane (stream_builder.h, Tiling::tpl) has no tile B at all: its
+  // accumulators hold channels 24 .. 47 of the wave
+  if (t.tpl == 1 || (t.pix_waves == 1 && t.tr * t.nseg <= t.rows_per_slab && opt.one_tile >= 0)) opt.one_tile = 1;
   else opt.one_tile = 0;
   size_t max_unit = 0;
   Program p = build_pass(g, t, rowptr, colidx, values, opt, 0, &max_unit);

@@ -19,8 +19,9 @@ namespace {
 // One candidate tiling of a concrete (H, W) cut of the image: `passes` workgroup columns per conv
 // group (0: as few as the accumulator file allows) and, for layers whose images fit a workgroup
 // tile, `nseg` whole images per workgroup (0: as many as fit).
-Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int passes, int nseg) {
+Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int passes, int nseg, int tpl = kTilesPerLane) {
   Tiling t;
+  t.tpl = tpl;
   t.H = g.H; t.W = g.W; t.OH = g.OH; t.OW = g.OW;
   // epilogue shifts: s = kc - pad_w must satisfy |s| <= 4 (one neighbouring quad)
   if (g.KW < 1 || g.KW > 5 || g.pad_w > 4 || g.KW - 1 - g.pad_w > 4) return t;
@@ -38,7 +39,7 @@ Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int 
   // and balanced over the passes: a layer with few output channels then gets a small pixel tile
   // per workgroup (more workgroups for the same batch) and every wave of it shares one staged
   // input tile, instead of a few workgroups whose waves each own 24 channels' worth of nothing.
-  const int gmax = kAccRegsPerTile / (4 * g.KW);
+  const int gmax = kAccRegsPerTile * (kTilesPerLane / tpl) / (4 * g.KW);
   const int mg = std::max(1, g.Mg);
   t.waves = waves_per_wg;
   t.oc_waves = 1;
@@ -49,7 +50,7 @@ Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int 
   t.n_ocg = (g.Mg + t.G - 1) / t.G;
   t.pix_waves = waves_per_wg / t.oc_waves;
   t.n_ocblk = (t.n_ocg + t.oc_waves - 1) / t.oc_waves;
-  t.rows_per_wg = t.pix_waves * kTilesPerLane * t.rows_per_slab;
+  t.rows_per_wg = t.pix_waves * tpl * t.rows_per_slab;
   if (g.OH <= t.rows_per_wg) {
     t.band_mode = false;
     t.tr = g.OH;
@@ -111,7 +112,7 @@ double launch_cost_us(const ConvGeom &g, const Tiling &t, int n_cu) {
   // 34.6 us with the walk and the stores switched off; rounds 1-2 assumed 50)
   static const double dma_bytes_per_us = (getenv("ESCOIN_DMA_GBPS") ? atof(getenv("ESCOIN_DMA_GBPS")) : 19.0) * 1e3;
   const double dma = (double)g.Cg * t.plane_ch_floats * 4.0 / dma_bytes_per_us;
-  const double epilogue = 0.15 * t.G * kTilesPerLane;
+  const double epilogue = 0.15 * t.G * t.tpl;
   const double per_tile = t.n_icb * 1.2 + std::max(walk, dma) + epilogue;
   const long tiles = t.band_mode ? (long)g.N * t.bands : ((long)g.N + t.nseg - 1) / t.nseg;
   const long cus = std::max(1, n_cu);
@@ -134,7 +135,7 @@ double launch_cost_us(const ConvGeom &g, const Tiling &t, int n_cu) {
 // The tiling of one concrete (H, W) cut: the cheapest of the candidates (more passes = fewer
 // output channels and a shorter stream per wave, but the input staged once more; fewer images per
 // workgroup = more workgroups for small batches, but emptier lanes).
-Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu) {
+Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu, bool one_tile_ok) {
   Tiling best = tile_with(g, waves_per_wg, lds_budget_bytes, 0, 0);
   if (!best.ok) return best;
   double best_cost = launch_cost_us(g, best, n_cu);
@@ -154,14 +155,31 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
     }
     if (best.G == 1) break;
   }
+  // One quad per lane (generated code, pointwise layers): where every row of the tile fits tile A
+  // anyway, the accumulators of tile B can hold more channels instead -- up to 48 per wave, 384 per
+  // workgroup column -- and a layer with 193 .. 384 output channels stages its input once, not twice.
+  // Taken only when it saves workgroup columns.
+  if (one_tile_ok && g.KH == 1 && g.KW == 1 && !best.band_mode && best.pix_waves == 1 &&
+      best.tr * best.nseg <= best.rows_per_slab && best.n_ocblk > 1) {
+    for (int passes = 1; passes < best.n_ocblk; ++passes) {
+      const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, passes, best.nseg, 1);
+      if (!t.ok || t.G < 1 || t.n_ocblk >= best.n_ocblk || t.band_mode || t.pix_waves != 1) continue;
+      const double c = launch_cost_us(g, t, n_cu);
+      if (c < best_cost * 0.97) {
+        best = t;
+        best_cost = c;
+        break;
+      }
+    }
+  }
   return best;
 }
 
 }  // namespace
 
-Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu) {
+Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu, bool one_tile_ok) {
   if (n_cu < 1) n_cu = 256;
-  Tiling best = tile_for(g, waves_per_wg, lds_budget_bytes, n_cu);
+  Tiling best = tile_for(g, waves_per_wg, lds_budget_bytes, n_cu, one_tile_ok);
   // A pointwise layer (1x1, no padding) does not care where the rows of an image break: its
   // H*W pixels are one contiguous run per channel.  These layers are bound by the LDS-DMA fill rate
   // (DESIGN.md 4.1), and a fill instruction costs the same whether its 16-byte slots carry pixels,
@@ -188,7 +206,7 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, 
       ConvGeom c = g;
       c.W = c.OW = w;
       c.H = c.OH = hw / w;
-      const Tiling t = tile_for(c, waves_per_wg, lds_budget_bytes, n_cu);
+      const Tiling t = tile_for(c, waves_per_wg, lds_budget_bytes, n_cu, one_tile_ok);
       if (!t.ok) continue;
       bool better = !best.ok;
       if (!better) {

@@ -47,7 +47,9 @@ struct Tiling {
   int G = 0;             // output channels per wave
   int n_ocg = 0;         // oc-groups per conv group = ceil(Mg / G)
   int n_ocblk = 0;       // workgroup columns per conv group = ceil(n_ocg / oc_waves)
-  int rows_per_wg = 0;   // pix_waves * 2 * rows_per_slab flattened rows
+  int tpl = kTilesPerLane;   // quads a lane owns: 2 (tile A, tile B), or 1 -- generated code only, pointwise
+                         // layers only: the whole accumulator file serves tile A, twice the channels per wave
+  int rows_per_wg = 0;   // pix_waves * tpl * rows_per_slab flattened rows
   int tr = 0;            // output rows per segment
   int nseg = 0;          // segments (whole images) per workgroup; 1 in band mode
   bool band_mode = false;// true: a workgroup covers `tr` rows of ONE image
@@ -64,7 +66,8 @@ struct Tiling {
 // lds_budget_bytes bounds the input planes only; the stream region is added on top.
 // n_cu: compute units of the device.  Among the candidate tilings (passes over the output
 // channels x images per workgroup) the one with the lowest estimated launch time is taken.
-Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu = 256);
+// one_tile_ok: tilings with one quad per lane may be chosen (the caller runs generated code).
+Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu = 256, bool one_tile_ok = false);
 
 // The same tiling with channel planes of `qpc` quads in LDS (>= the tiling's own: padding quads are
 // staged like rows past the image) and the input-channel blocks recomputed for the budget.

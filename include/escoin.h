@@ -153,6 +153,13 @@ ESCOIN_API size_t escoin_plan_workspace_bytes(const escoin_plan *plan);
 /* Name of the device kernel the plan launches (the symbol rocprofv3 reports). */
 ESCOIN_API const char *escoin_plan_kernel_name(const escoin_plan *plan);
 
+/* One line describing how the plan's fast kernel tiles the layer (channels per wave, workgroup columns,
+ * images per tile, quads per lane, input-channel blocks, plane buffers, generated code or weight
+ * stream); "" for plans that run the generic / dense / lowered kernel.  Diagnostics only: the
+ * reference has no counterpart (its kernels are fixed-shape, math_functions.cu:524-587).  The
+ * string lives as long as the plan and changes with weight_align / set_csr / set_option. */
+ESCOIN_API const char *escoin_plan_tiling_info(const escoin_plan *plan);
+
 /* Forward_gpu body for one bottom/top pair, whole batch, asynchronous on `stream`:
  *   top[n][oc] = sconv(bottom[n], CSR)[oc] (+ bias[oc]) (then ReLU if fuse_relu)
  * bottom: n_images x C x H x W, top: n_images x M x OH x OW, bias: M floats or NULL.

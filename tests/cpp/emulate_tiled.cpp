@@ -198,7 +198,7 @@ static int run(const Case &cs, bool use_jit) {
   g.density = 1.0f - cs.sparsity;
   // ncu = 1 (default): as on a full chip with a large batch, the fewest passes win; the cases
   // with ncu = 256 see a nearly empty chip and spread the channels over many workgroups
-  Tiling t = choose_tiling(g, cs.waves, cs.lds, cs.ncu);
+  Tiling t = choose_tiling(g, cs.waves, cs.lds, cs.ncu, use_jit);   // (one quad per lane: generated code only)
   if (!t.ok) { printf("tiling rejected\n"); return 2; }
   const int kdim = g.Cg * g.KH * g.KW;
   std::vector<float> w((size_t)g.M * kdim), x((size_t)g.N * g.C * g.H * g.W), bias(g.M);
@@ -319,9 +319,9 @@ static int run(const Case &cs, bool use_jit) {
               JitWave jw;
               std::vector<uint32_t> laneA(64);
               for (int lane = 0; lane < 64; ++lane) {
-                const int fr = (pw * 2) * t.rows_per_slab + lane / t.S4;
+                const int fr = (pw * t.tpl) * t.rows_per_slab + lane / t.S4;
                 laneA[lane] = (uint32_t)(((size_t)fr * t.RS + 4 * (lane % t.S4)) * 4);
-                if (t.rows_per_slab * t.RS * 4 != 1024) { printf("tile B is not tile A + 1 KiB\n"); return 3; }
+                if (t.tpl == 2 && t.rows_per_slab * t.RS * 4 != 1024) { printf("tile B is not tile A + 1 KiB\n"); return 3; }
                 for (int r = 0; r < kAccAll; ++r) jw.v[(size_t)lane * 256 + 64 + r] = acc[((size_t)wave * 64 + lane) * kAccAll + r];
               }
               const size_t ui = ((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk;
@@ -437,9 +437,11 @@ static int run(const Case &cs, bool use_jit) {
             if (ocg * t.G + gl >= g.Mg) break;
             const int m = (int)ws2.chan[((size_t)cg * t.n_ocg + ocg) * t.G + gl];   // channel in this slot
             const int oc = cg * g.Mg + m;
-            for (int tl = 0; tl < 2; ++tl)
+            // (one quad per lane: slot gl >= 24 lives in what would be tile B's registers -- the
+            // accumulator file is one run of 192 registers, indexed 4 * (gl * KW + kc) either way)
+            for (int tl = 0; tl < t.tpl; ++tl)
               for (int lane = 0; lane < 64; ++lane) {
-                const int fr = (pw * 2 + tl) * t.rows_per_slab + lane / t.S4;
+                const int fr = (pw * t.tpl + tl) * t.rows_per_slab + lane / t.S4;
                 const int yl = fr / t.nseg, seg = fr % t.nseg, j = lane % t.S4;
                 if (yl >= t.tr) continue;
                 int n, y;
@@ -485,9 +487,9 @@ static int run(const Case &cs, bool use_jit) {
     maxref = std::fmax(maxref, std::fabs(want[i]));
   }
   const double rel = maxerr / std::fmax(1e-6, maxref);
-  printf("%sN%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
+  printf("%sN%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: tpl=%d S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
          "groups=%ld recs=%ld recs/group=%.2f dma=%ld rel_err=%.2e\n",
-         use_jit ? "jit " : "", cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.S4, t.G,
+         use_jit ? "jit " : "", cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.tpl, t.S4, t.G,
          t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes,
          ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, dma_checked, rel);
   if (use_jit && jdma.on && dma_checked == 0) { printf("jit dma: nothing was checked\n"); return 3; }
@@ -522,6 +524,9 @@ int main() {
       {5, 30, 7, 7, 48, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 256},    // empty chip, pointwise
       {40, 16, 7, 7, 64, 1, 1, 0, 0, 1, 0.9f, 8, 65536, 8},     // 8 CUs: images per workgroup vs passes
       {1, 48, 56, 56, 64, 1, 1, 0, 0, 1, 0.97f, 8, 65536, 256}, // one channel per wave, units of 0-2 rows: the code's own plane DMA goes out in the tail
+      {32, 300, 14, 14, 256, 1, 1, 0, 0, 1, 0.95f, 8, 65536, 32},    // 256 output channels, one image per tile: generated code takes one quad per lane, 32 channels per wave
+      {16, 400, 7, 7, 384, 1, 1, 0, 0, 1, 0.97f, 8, 65536, 16},    // 384: 48 channels per wave, output rows that are not whole quads
+      {16, 10, 4, 4, 300, 1, 1, 0, 0, 1, 0.8f, 8, 65536, 16},    // 300: a ragged last slot range (38 channels per wave, 4 in the last)
   };
   int bad = 0;
   for (const Case &c : cases) {

@@ -99,7 +99,7 @@ def _config_sets(synth):
             ("resnet50", synth.resnet50_3x3(N=256)), ("googlenet", synth.googlenet_1x1(N=256))]
 
 
-def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None, kernel=None):
+def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None, kernel=None, relu=False):
     """Forward of the WHOLE config batch on device-generated input; images {0, 1 and 3 (inside the
     first multi-image tile), N/2, N-2, N-1} are checked against the oracle (<= 1e-4)."""
     dev = torch.device("cuda:0")
@@ -118,7 +118,7 @@ def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None
     xs, got = x[idx].cpu().numpy(), top[idx].cpu().numpy()
     g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
                     s.dil_h, s.dil_w, s.group)
-    want = oracle.conv_forward(g, xs, w, b, gate=False, threads=4)
+    want = oracle.conv_forward(g, xs, w, b, relu=relu, gate=False, threads=4)
     err = rel_err(got, want)
     name = plan.kernel_name
     if own:
@@ -691,3 +691,25 @@ def test_global_batch_2048_on_one_gpu(pkg, oracle, synth, torch_cuda):
         del x, top
         plan.close()
     torch.cuda.empty_cache()
+
+
+def test_pointwise_layers_with_one_quad_per_lane(pkg, oracle, synth, torch_cuda):
+    """Pointwise layers with 193 .. 384 output channels on small images: generated code gives a lane ONE
+    quad and the whole accumulator file to it (up to 48 channels per wave, one workgroup column instead of
+    two; Tiling::tpl, stream_builder.h).  Slots 24 .. 47 of a wave live in what are tile B's registers
+    elsewhere and leave through their own epilogue paths: the asm one (output rows of whole quads,
+    14 x 14 walked as 1 x 196) and the element-wise one (13 x 13 as 1 x 169), with bias, with fused ReLU,
+    with a ragged last slot range -- whole batch on the GPU, six images each against the oracle."""
+    cases = [synth.shape("pw14_256", 256, 512, 14, 14, 256, 1, sparsity=0.95),
+             synth.shape("pw13_256", 256, 256, 13, 13, 256, 1, sparsity=0.95),
+             synth.shape("pw13_300", 256, 832, 13, 13, 300, 1, sparsity=0.95, bias=False),
+             synth.shape("pw14_200", 256, 512, 14, 14, 200, 1, sparsity=0.95)]
+    for k, s in enumerate(cases):
+        for relu in (False, True):
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=pkg.KERNEL_JIT)
+            plan.weight_align(synth.pruned_weights(s, 9100 + k))
+            info = plan.tiling_info
+            assert "generated-code" in info and "tpl=1" in info and "columns=1" in info, (s.name, info)
+            err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 9100 + k, plan=plan, relu=relu)
+            assert err <= TOL, "%s via %s: %g (%s)" % (s.name, name, err, info)
+            plan.close()
