@@ -476,7 +476,10 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     plain = [step_ms[k] for k in range(args.steps) if k not in ev]
     ms_sampled = float(np.mean([step_ms[k] for k in sampled]))
     ms_plain = float(np.mean(plain)) if plain else ms_sampled
-    event_ms = max(0.0, (ms_sampled - ms_plain) / len(layers))      # what one event between two launches costs
+    # what one event between two launches costs the launches of a sampled step: their durations, event to
+    # event, add up to this much more than a step without them takes (so the corrected ones add up to it)
+    ms_launches = float(np.mean([ev[k][0].elapsed_time(ev[k][len(layers)]) for k in sampled]))
+    event_ms = max(0.0, (ms_launches - ms_plain) / len(layers)) if plain else 0.0
     for li, (s, plan, bias, si, lid) in enumerate(layers):
         ms = [ev[k][li].elapsed_time(ev[k][li + 1]) for k in sampled]
         m = max(float(np.mean(ms)) - event_ms, 1e-6)

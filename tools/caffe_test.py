@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--dense-gate", action="store_true",
                     help="honour the reference's density > 0.2 -> dense GEMM gate")
     ap.add_argument("--check", action="store_true", help="compare with the CPU oracle (first 2 images)")
+    ap.add_argument("--tilings", action="store_true", help="print how every layer's plan tiles it (escoin_plan_tiling_info)")
     args = ap.parse_args()
 
     pkg = ge.load_package()
@@ -287,6 +288,9 @@ def main():
         print("%-26s %-34s %9.1f %9.2f %8.0f %14.1f" % (name, plans[li].kernel_name[:34], us,
                                                         synth.flops(s) / us * 1e-6,
                                                         synth.algorithmic_bytes(s) / us * 1e-3, align_ms[li]))
+    if args.tilings:
+        for li, (name, s) in enumerate(layers):
+            print("%-26s %s" % (name, plans[li].tiling_info or "(no tiled plan: %s)" % plans[li].kernel_name))
 
     if args.check:
         oracle = ge.load_oracle()
