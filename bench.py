@@ -74,9 +74,9 @@ class HipBackend(object):
     name = "hip"
     dist_backend = "nccl"
 
-    def __init__(self, pkg, local_rank, kernel):
+    def __init__(self, pkg, local_rank, kernel, stream_stores=False):
         import torch
-        self.torch, self.pkg, self.kernel = torch, pkg, kernel
+        self.torch, self.pkg, self.kernel, self.stream_stores = torch, pkg, kernel, stream_stores
         if not torch.cuda.is_available() or pkg.device_count() < 1:
             raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
         # (one rank per GPU under the driver; ranks wrap around when a rehearsal runs more ranks than
@@ -86,7 +86,8 @@ class HipBackend(object):
         self.device = torch.device("cuda", dev_index)
 
     def make_plan(self, shape):
-        return self.pkg.Plan(self.pkg.ConvDesc.from_shape(shape), kernel=self.kernel)
+        opts = {"stream_stores": 1} if self.stream_stores else {}
+        return self.pkg.Plan(self.pkg.ConvDesc.from_shape(shape), kernel=self.kernel, **opts)
 
     def synchronize(self):
         self.torch.cuda.synchronize()
@@ -564,7 +565,8 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         "config": {"workload": "%s @%d%% sparsity, batch %d/GPU, fp32" %
                                (wl_name, round(100 * shapes[0].sparsity), per_gpu_batch),
                    "global_batch": global_batch, "layers_per_step": len(layers),
-                   "kernel": args.kernel, "parallelism": "batch-sharded x%d" % world,
+                   "kernel": args.kernel, "stream_stores": bool(getattr(args, "stream_stores", False)),
+                   "parallelism": "batch-sharded x%d" % world,
                    "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None},
         "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None,
         "backend": be.name, "dist_backend": (be.dist_backend if test_be(be) else args.dist_backend) if world > 1 else None,
@@ -596,6 +598,10 @@ def parse_args(argv=None):
                     help="auto = generated code (jit) where available; tiled = the LDS-staged stream kernel")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stream-stores", action="store_true",
+                    help="plan option stream_stores = 1: pointwise layers write their top blob with non-temporal "
+                         "stores (the layers of a step have no consumer here; a net's next layer reads the blob, "
+                         "and the default keeps it cached -- tools/producer_consumer.py)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the driver's runs); gloo lets two ranks share one GPU for a rehearsal")
     args = ap.parse_args(argv)
@@ -693,7 +699,7 @@ def main():
         be = load_test_backend(test_backend, local_rank)
         args.dist_backend = be.dist_backend
     else:
-        be = HipBackend(pkg, local_rank, kernel)
+        be = HipBackend(pkg, local_rank, kernel, stream_stores=args.stream_stores)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":

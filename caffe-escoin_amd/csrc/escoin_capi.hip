@@ -277,6 +277,11 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
     p->dense_threshold_pct = value;
     return ESCOIN_OK;
   }
+  if (!strcmp(key, "stream_stores")) {
+    if (value < -1 || value > 1) return fail(ESCOIN_EINVAL, "stream_stores must be -1, 0 or 1");
+    p->stream_stores = value;
+    return ESCOIN_OK;
+  }
   if (!strcmp(key, "kernel")) {
     if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_JIT)
       return fail(ESCOIN_EINVAL, "unknown kernel id");

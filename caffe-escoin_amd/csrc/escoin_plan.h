@@ -101,6 +101,7 @@ struct escoin_plan {
   unsigned long long dense_mask = 0, sparse_mask = ~0ull;
   int n_dense_groups = 0, n_sparse_groups = 0;
   int dense_threshold_pct = -1;   // option "dense_threshold_pct" (-1: the measured default)
+  int stream_stores = -1;         // option "stream_stores": pointwise layers write the top blob with non-temporal stores (1), never (0), by size (-1)
 
   // LOWERED_SPARSE comparator (sconv_lowered.hip): column buffer, grown on demand
   float *d_col = nullptr;

@@ -57,6 +57,7 @@ MAX_SLOTS2 = 6
 ABL = set()                  # timing-only ablations (see main())
 PRIO_HI = 1                  # priority of a wave's even groups (odd groups run at 0)
 PRIO_QUADS = True            # four-group runs: one priority switch per two groups
+STORE_MOD = ""               # ESC_GEN_STORE_MOD: modifier on the epilogues' stores (experiments: " nt", " sc1")
 PRIO_BASE = 0                # added to both (the second-dispatched half of the workgroup: constant level 1, see main())
 
 
@@ -377,7 +378,8 @@ def main():
     import os
     if os.environ.get("ESC_GEN_NOPRIO"):
         ABL.add("noprio")
-    global PRIO_HI, PRIO_QUADS, ALIGN
+    global PRIO_HI, PRIO_QUADS, ALIGN, STORE_MOD
+    STORE_MOD = os.environ.get("ESC_GEN_STORE_MOD", "")
     if os.environ.get("ESC_GEN_ALIGN", "") != "":
         ALIGN = int(os.environ["ESC_GEN_ALIGN"])
     PRIO_QUADS = os.environ.get("ESC_GEN_PRIO_QUADS", "1") == "1"
@@ -498,7 +500,7 @@ def main():
                     "s_add_u32 s38, s34, s36",
                     "s_addc_u32 s39, s35, 0",
                     "s_mov_b64 exec, %[ok]",
-                    "global_store_dwordx4 %%[voff], v[%d:%d], s[38:39]" % (C0, C0 + 3),
+                    "global_store_dwordx4 %%[voff], v[%d:%d], s[38:39]%s" % (C0, C0 + 3, STORE_MOD),
                 ]
                 if r:
                     lines.append("s_mov_b64 exec, %[okp]")
@@ -565,7 +567,7 @@ def main():
                     "s_add_u32 s38, s34, s36",
                     "s_addc_u32 s39, s35, 0",
                     "s_mov_b64 exec, %[ok]",
-                    "global_store_dwordx4 %%[voff], v[%d:%d], s[38:39]" % (C0, C0 + 3),
+                    "global_store_dwordx4 %%[voff], v[%d:%d], s[38:39]%s" % (C0, C0 + 3, STORE_MOD),
                 ]
                 if r:
                     lines.append("s_mov_b64 exec, %[okp]")
@@ -583,7 +585,9 @@ def main():
             emit_macro(out, "ESC_EPI5S_%d_%d" % (tile, r), lines)
     # ESC_EPI1S_<tile>: the same for pointwise layers (one class per channel, up to 24 channels per
     # wave, nothing to shift) whose output rows are whole quads
-    for tile, base in ((0, ACC_A), (1, ACC_B)):
+    # ESC_EPI1SN_<tile>: the same with non-temporal stores (plan option "stream_stores")
+    for tile, base, mod, mname in ((0, ACC_A, STORE_MOD, "ESC_EPI1S"), (1, ACC_B, STORE_MOD, "ESC_EPI1S"),
+                                   (0, ACC_A, " nt", "ESC_EPI1SN"), (1, ACC_B, " nt", "ESC_EPI1SN")):
         lines = ["s_mov_b64 s[32:33], exec", "s_mov_b64 s[34:35], %[base]", "s_mov_b64 exec, %[ok]"]
         ng = NACC_TILE // 4
         for g in range(ng):
@@ -602,7 +606,7 @@ def main():
             lines += ["v_max_f32 v%d, 0, v%d" % (C0 + e, C0 + e) for e in range(4)]
             lines += [
                 "ESC_PR%d_%d_%%=:" % (tile, g),
-                "global_store_dwordx4 %%[voff], v[%d:%d], s[34:35]" % (C0, C0 + 3),
+                "global_store_dwordx4 %%[voff], v[%d:%d], s[34:35]%s" % (C0, C0 + 3, mod),
             ]
             if g + 1 < ng:
                 lines += [
@@ -613,7 +617,7 @@ def main():
                 ]
         lines.append("ESC_PX%d_%%=:" % tile)
         lines.append("s_mov_b64 exec, s[32:33]")
-        emit_macro(out, "ESC_EPI1S_%d" % tile, lines)
+        emit_macro(out, "%s_%d" % (mname, tile), lines)
     out.write("#define ESC_EPI3S_CLOBBERS \"memory\", \"scc\", \"s32\", \"s33\", \"s34\", \"s35\", \"s36\", \"s37\", \"s38\", \"s39\", ")
     out.write(", ".join('\"v%d\"' % i for i in range(ACC_A, 256)))
     out.write("\n")

@@ -119,7 +119,12 @@ ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
  *                  (-1 = the built-in measured crossover; 100 = never);
  *   "tiling_batch" = choose the tiled kernel's tiling as for a batch of this many images
  *                  (0 = desc.N).  Results do not depend on it; tests use it to run small inputs
- *                  through the weight stream / tile shapes of the full-size configurations. */
+ *                  through the weight stream / tile shapes of the full-size configurations;
+ *   "stream_stores" = 1: pointwise (1x1, stride 1, pad 0) layers write the top blob with non-temporal
+ *                  stores -- for a blob nothing on the device reads next (3-4 % on a sequence of
+ *                  independent layers); 0 / -1 (default): ordinary stores, which leave the blob in
+ *                  L2 / Infinity Cache for the layer that consumes it (as the reference's kernels
+ *                  do, math_functions.cu:524-587).  Results are the same either way. */
 ESCOIN_API int escoin_plan_set_option(escoin_plan *plan, const char *key, int value);
 
 /* WeightAlign(): dense blobs_[0] (M x C/g x KH x KW, zeros = pruned) -> per-group CSR

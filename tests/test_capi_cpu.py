@@ -74,6 +74,10 @@ def test_plan_lifecycle_and_options_on_host(pkg):
     plan.set_option("tiling_batch", 256)
     plan.set_option("dense_threshold_pct", 30)
     plan.set_option("dense_gate", 1)
+    for v in (-1, 0, 1):
+        plan.set_option("stream_stores", v)
+    with pytest.raises(pkg.EscoinError):
+        plan.set_option("stream_stores", 2)
     with pytest.raises(pkg.EscoinError):
         plan.set_option("tiling_batch", -5)
     with pytest.raises(pkg.EscoinError):

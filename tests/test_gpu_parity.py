@@ -706,10 +706,34 @@ def test_pointwise_layers_with_one_quad_per_lane(pkg, oracle, synth, torch_cuda)
              synth.shape("pw14_200", 256, 512, 14, 14, 200, 1, sparsity=0.95)]
     for k, s in enumerate(cases):
         for relu in (False, True):
-            plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=pkg.KERNEL_JIT)
+            # (the ReLU runs also write the top blob with non-temporal stores: option "stream_stores")
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=pkg.KERNEL_JIT, stream_stores=int(relu))
             plan.weight_align(synth.pruned_weights(s, 9100 + k))
             info = plan.tiling_info
             assert "generated-code" in info and "tpl=1" in info and "columns=1" in info, (s.name, info)
             err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 9100 + k, plan=plan, relu=relu)
             assert err <= TOL, "%s via %s: %g (%s)" % (s.name, name, err, info)
             plan.close()
+
+
+def test_stream_stores_option_changes_nothing_but_the_store_instruction(pkg, oracle, synth, torch_cuda):
+    """Plan option "stream_stores" (non-temporal stores of a pointwise layer's top blob): same results, bit
+    for bit, on the asm epilogue (rows of whole quads), the element-wise one (7 x 7) and both tiles."""
+    dev = torch_cuda.device("cuda:0")
+    for k, s in enumerate([synth.shape("ss28", 8, 48, 28, 28, 40, 1, sparsity=0.9),
+                           synth.shape("ss7", 40, 64, 7, 7, 72, 1, sparsity=0.9),
+                           synth.shape("ss56", 3, 16, 56, 56, 24, 1, sparsity=0.8, bias=False)]):
+        w, b = synth.pruned_weights(s, 9300 + k), synth.bias_vector(s, 9400 + k)
+        x = torch_cuda.from_numpy(synth.activations(s, 9500 + k)).to(dev)
+        bias = torch_cuda.from_numpy(b).to(dev) if b is not None else None
+        outs = []
+        for ss in (0, 1):
+            for kernel in (pkg.KERNEL_JIT, pkg.KERNEL_TILED):
+                plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel, stream_stores=ss)
+                plan.weight_align(w)
+                outs.append(plan.forward(x, bias).cpu().numpy())
+                plan.close()
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, s.dil_h, s.dil_w, s.group)
+        want = oracle.conv_forward(g, synth.activations(s, 9500 + k), w, b, gate=False)
+        assert rel_err(outs[0], want) <= TOL
+        assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3]), s.name
