@@ -713,6 +713,16 @@ def test_pointwise_layers_with_one_quad_per_lane(pkg, oracle, synth, torch_cuda)
             assert "generated-code" in info and "tpl=1" in info and "columns=1" in info, (s.name, info)
             err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 9100 + k, plan=plan, relu=relu)
             assert err <= TOL, "%s via %s: %g (%s)" % (s.name, name, err, info)
+            if k == 0:      # a partial batch on the same plan: tiles past the last image store nothing
+                dev = torch_cuda.device("cuda:0")
+                x5 = torch_cuda.from_numpy(synth.activations(s._replace(N=5), 9200)).to(dev)
+                b = synth.bias_vector(s, 9100 + k + 1)
+                guard = torch_cuda.full((6, s.M, s.H, s.W), 7.0, device=dev)
+                plan.forward(x5, torch_cuda.from_numpy(b).to(dev), guard[:5])
+                g = oracle.geom(s.C, s.H, s.W, s.M, 1, 1, 0, 0, 1, 1, 1, 1, 1)
+                want = oracle.conv_forward(g, x5.cpu().numpy(), synth.pruned_weights(s, 9100 + k), b, relu=relu, gate=False)
+                assert rel_err(guard[:5].cpu().numpy(), want) <= TOL
+                assert float(guard[5].min()) == 7.0 and float(guard[5].max()) == 7.0
             plan.close()
 
 
