@@ -431,15 +431,25 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
             if events is not None:
                 events[li + 1].record()
 
+    # The chip's clocks take tens of milliseconds of load to settle (the first 100 launches of a layer run
+    # 10-15 % slower than the next hundred): a short run's W warm-up steps may be over before that.  Before
+    # them, untimed and outside the W + K steps the command asks for, the same step runs for a fixed
+    # wall-clock time.
+    if args.settle_ms > 0:
+        be.synchronize()
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            step()
+            be.synchronize()
     for _ in range(args.warmup):
         step()
     # Events inside the timed region: ONE per step boundary in every step, and one between every two
-    # launches in a SAMPLE of the steps (10 of the default 100, a fifth of a short run).  An event
+    # launches in a SAMPLE of the steps (10 of the default 100, 2 of a run of 20).  An event
     # between two kernels is not free -- 1.5 us per launch on the ResNet set, 2.9 us on GoogLeNet's 39
     # short launches (8 % of that step, tools/gap_probe.py) -- and a caller of the path records none,
     # so most steps run as a caller's would.  What an event costs is measured here, as the difference
     # between the sampled and the other steps, and taken off the per-launch durations.
-    n_sampled = min(10, max(1, args.steps // 5))
+    n_sampled = min(10, max(2, args.steps // 10)) if args.steps >= 4 else 1
     stride = max(1, args.steps // n_sampled)
     sampled = [k for k in range(args.steps) if k % stride == 0][:n_sampled]
     step_ev = [be.event() for _ in range(args.steps + 1)]
@@ -558,7 +568,7 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     out = {
         "metric": "conv-layer fwd images/sec", "value": round(value, 1), "unit": "images/s",
         "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
-        "steps": args.steps, "warmup": args.warmup,
+        "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -589,6 +599,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per workload, see DEFAULT_STEPS)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: per workload)")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="run the step untimed for this long before the warm-up steps (clock settling; 0: not at all)")
     ap.add_argument("--workload", default="resnet50")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=None,
