@@ -200,17 +200,12 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
 static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,
                           const std::vector<std::vector<int>> &colidx,
                           const std::vector<std::vector<float>> &values, const Options &opt, int n_pref,
-                          size_t *max_unit_bytes) {
+                          size_t *max_unit_bytes, const std::vector<uint32_t> &chan) {
   Program p;
   std::vector<size_t> patches;
   const size_t n_units = (size_t)g.group * t.n_ocg * t.n_icb;
   p.unit_off.assign(n_units, 0u);
-  p.chan.reserve((size_t)g.group * t.n_ocg * t.G);
-  for (int cg = 0; cg < g.group; ++cg) {
-    // instructions of generated code per nonempty row (two reads, a wait) and per nonzero
-    const std::vector<uint32_t> sl = balance_channels(g, t, rowptr[cg], colidx[cg], 3.0, 5.0);
-    p.chan.insert(p.chan.end(), sl.begin(), sl.end());
-  }
+  p.chan = chan;
   const int rows_per_blk = t.icb * g.KH;
   std::vector<Row> rows(rows_per_blk), live;
   std::vector<Piece> pieces;
@@ -299,14 +294,22 @@ Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std:
   // accumulators hold channels 24 .. 47 of the wave
   if (t.tpl == 1 || (t.pix_waves == 1 && t.tr * t.nseg <= t.rows_per_slab && opt.one_tile >= 0)) opt.one_tile = 1;
   else opt.one_tile = 0;
+  // the channel deal (once: both passes below generate code for the same deal)
+  std::vector<uint32_t> chan;
+  chan.reserve((size_t)g.group * t.n_ocg * t.G);
+  for (int cg = 0; cg < g.group; ++cg) {
+    // instructions of generated code per nonempty row (two reads, a wait) and per nonzero
+    const std::vector<uint32_t> sl = balance_channels(g, t, rowptr[cg], colidx[cg], 3.0, 5.0);
+    chan.insert(chan.end(), sl.begin(), sl.end());
+  }
   size_t max_unit = 0;
-  Program p = build_pass(g, t, rowptr, colidx, values, opt, 0, &max_unit);
+  Program p = build_pass(g, t, rowptr, colidx, values, opt, 0, &max_unit, chan);
   if (!opt.prefetch || p.overflow) return p;
   // every unit carries the same number of touches: enough for the longest unit (its own touches included)
   int n_pref = 1;
   while ((size_t)n_pref * 4096 < max_unit + 16 + (size_t)n_pref * 20) ++n_pref;
   max_unit = 0;
-  return build_pass(g, t, rowptr, colidx, values, opt, n_pref, &max_unit);
+  return build_pass(g, t, rowptr, colidx, values, opt, n_pref, &max_unit, chan);
 }
 
 }  // namespace jit
