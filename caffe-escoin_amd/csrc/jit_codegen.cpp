@@ -27,6 +27,7 @@ int dma_period(int qpc, int max_period, double slack, int *padded) {
 Options options_from_env() {
   Options o;
   if (const char *e = getenv("ESCOIN_JIT_DEPTH")) o.depth = std::max(1, std::min(2, atoi(e)));
+  if (const char *e = getenv("ESCOIN_JIT_DEPTH1")) o.depth_one_tile = std::max(1, std::min(5, atoi(e)));
   if (const char *e = getenv("ESCOIN_JIT_HOIST")) o.hoist_weight = atoi(e) != 0;
   if (const char *e = getenv("ESCOIN_JIT_PRIO_ROWS")) o.prio_rows = std::max(0, atoi(e));
   if (const char *e = getenv("ESCOIN_JIT_PRIO_WAVES")) o.prio_waves = std::max(0, atoi(e));
@@ -93,12 +94,18 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     }
   }
   const int n = (opt.ablate & 8) ? 0 : (int)rows.size();
-  const int depth = opt.depth;
+  // Without a tile B the 24 input registers hold SIX quads instead of three pairs: rows are read five
+  // ahead.  A row of such a layer (pointwise, 95 % sparse) carries one or two nonzeros -- 10-25 cycles of
+  // FMAs -- and an LDS read takes well over a hundred to land: two rows of read-ahead left the walk
+  // waiting for LDS latency on every row.
+  const int n_sets = opt.one_tile > 0 ? 2 * kInSets : kInSets;
+  const int set_regs = opt.one_tile > 0 ? 4 : 8;
+  const int depth = opt.one_tile > 0 ? std::max(1, std::min(opt.depth_one_tile, n_sets - 1)) : opt.depth;
   Lds lds{c, 0, 0, opt.ablate};
   std::vector<int> row_id(n, -1);       // issue id of a row's second read
   auto issue = [&](int k) {
     if (opt.ablate & 2) return;
-    const int base = kVIn0 + 8 * (k % kInSets);
+    const int base = kVIn0 + set_regs * (k % n_sets);
     enc_ds_read_b128(c, base, kVAddrA, rows[k].lds_off);
     lds.issue();
     if (opt.one_tile) { row_id[k] = lds.issued - 1; return; }
@@ -168,7 +175,7 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     if (opt.ablate & 2) enc_waitcnt_lgkm(c, 0);
     else lds.wait_for(row_id[k]);
     issue_pieces(k);
-    const int xa = kVIn0 + 8 * (k % kInSets), xb = xa + 4;
+    const int xa = kVIn0 + set_regs * (k % n_sets), xb = xa + 4;
     for (int j = first_of_row[k]; j < first_of_row[k + 1]; ++j) {
       if (opt.ablate & 4) {
       } else if (opt.hoist_weight) {
