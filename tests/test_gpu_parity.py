@@ -747,3 +747,35 @@ def test_stream_stores_option_changes_nothing_but_the_store_instruction(pkg, ora
         want = oracle.conv_forward(g, synth.activations(s, 9500 + k), w, b, gate=False)
         assert rel_err(outs[0], want) <= TOL
         assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3]), s.name
+
+
+def test_randomised_pointwise_layers_with_many_output_channels(pkg, oracle, synth, torch_cuda):
+    """Seeded random pointwise layers with 130 .. 400 output channels on small images, tiled as for a
+    batch of 256 (one image or a few per workgroup, packed single-row planes, no tile B, one quad per
+    lane with up to 48 channels per wave where it saves a workgroup column) but run on 1 .. 9 images:
+    every image of the small batch is checked, with and without bias, ReLU and streaming stores."""
+    rng = np.random.RandomState(77)
+    S = synth.shape
+    tpl1 = 0
+    for k in range(24):
+        H = int(rng.choice([3, 4, 5, 6, 7, 9, 12, 13, 14, 15]))
+        W = H if rng.randint(3) else int(rng.randint(2, 17))
+        C = int(rng.randint(40, 200))
+        M = int(rng.randint(130, 401))
+        N = int(rng.randint(1, 10))
+        sp = float(rng.choice([0.9, 0.95, 0.97]))
+        relu = bool(rng.randint(2))
+        s = S("pwr%d" % k, N, C, H, W, M, 1, sparsity=sp, bias=bool(rng.randint(2)))
+        w, b, x = synth.pruned_weights(s, 9600 + k), synth.bias_vector(s, 9700 + k), synth.activations(s, 9800 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, 1, 1, 0, 0, 1, 1, 1, 1, 1)
+        want = oracle.conv_forward(g, x, w, b, relu=relu, gate=False)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=pkg.KERNEL_JIT, tiling_batch=256,
+                        stream_stores=int(rng.randint(2)))
+        plan.weight_align(w)
+        info = plan.tiling_info
+        tpl1 += "tpl=1" in info
+        dev = torch_cuda.device("cuda:0")
+        got = plan.forward(torch_cuda.from_numpy(x).to(dev), torch_cuda.from_numpy(b).to(dev) if b is not None else None).cpu().numpy()
+        plan.close()
+        assert rel_err(got, want) <= TOL, "%s %s: %g (%s)" % (s.name, (N, C, H, W, M, sp, relu), rel_err(got, want), info)
+    assert tpl1 >= 4, tpl1        # some of them must have taken one quad per lane
