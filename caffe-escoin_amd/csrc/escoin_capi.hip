@@ -183,14 +183,21 @@ static int upload(escoin_plan *p, hipStream_t stream) {
     // scalar move per nonzero is a larger share of the walk.  ESCOIN_JIT_MAX_DENSITY_PCT moves the cut.
     static const int jit_max_density_pct = getenv("ESCOIN_JIT_MAX_DENSITY_PCT") ? atoi(getenv("ESCOIN_JIT_MAX_DENSITY_PCT")) : 18;
     double dens_sparse = 0;
+    long nz_sparse = 0;
     {
-      long nz = 0, ng = 0;
+      long ng = 0;
       for (int grp = 0; grp < G; ++grp)
-        if (!dense[grp]) { nz += (long)p->colidx[grp].size(); ++ng; }
-      dens_sparse = ng ? (double)nz / (per_group * ng) : 0.0;
+        if (!dense[grp]) { nz_sparse += (long)p->colidx[grp].size(); ++ng; }
+      dens_sparse = ng ? (double)nz_sparse / (per_group * ng) : 0.0;
     }
+    // ... and up to 25 % density where the whole layer's code stays under ~4 MB (40 bytes per nonzero: the
+    // L2 of an XCD holds it): AlexNet's conv2 / conv5 at 80 % sparsity run generated code 1-6 % faster than
+    // the stream, its conv3 / conv4 (7 and 5 MB of code) 9-14 % slower (profiles/r03_jit_vs_stream.md).
+    static const long jit_small_nnz = getenv("ESCOIN_JIT_SMALL_NNZ") ? atol(getenv("ESCOIN_JIT_SMALL_NNZ")) : 100000;
+    const bool sparse_enough = dens_sparse * 100.0 <= jit_max_density_pct ||
+                               (dens_sparse <= 0.25 && nz_sparse <= jit_small_nnz);
     const bool try_jit = p->kernel_choice == ESCOIN_KERNEL_JIT ||
-                         (p->kernel_choice == ESCOIN_KERNEL_AUTO && jit_available() && dens_sparse * 100.0 <= jit_max_density_pct);
+                         (p->kernel_choice == ESCOIN_KERNEL_AUTO && jit_available() && sparse_enough);
     int rc = ESCOIN_OK;
     if (try_jit) {
       rc = tiled_build(p, stream, true);
