@@ -127,15 +127,23 @@ def layer_weight_seed(lid):
 
 def build_layers(be, pkg, synth, shapes, rank, world):
     """WeightAlign on rank 0, broadcast of the CSR (RCCL on the GPU box), set_csr elsewhere.
-    Returns [(shape, plan, bias, shape_index, layer_id)], seconds spent in the broadcast."""
+    Returns [(shape, plan, bias, shape_index, layer_id)] and the one-time costs: seconds in the
+    broadcast, per-layer WeightAlign milliseconds (rank 0: dense -> CSR -> tiling, channel deal,
+    generated code, code object), per-layer set_csr milliseconds on a receiver (the same minus
+    dense -> CSR), generated-code bytes."""
     torch = be.torch
     layers, t_bcast, lid = [], 0.0, 0
+    setup = {"align_ms": [], "receive_ms": [], "code_bytes": 0, "device_bytes": 0}
     for si, s in enumerate(shapes):
         for rep in range(s.count):
             plan = be.make_plan(s)
             mg = s.M // s.group
             if rank == 0:
-                plan.weight_align(synth.pruned_weights(s, layer_weight_seed(lid)))
+                w = synth.pruned_weights(s, layer_weight_seed(lid))
+                t0 = time.perf_counter()
+                plan.weight_align(w)
+                be.synchronize()
+                setup["align_ms"].append((time.perf_counter() - t0) * 1e3)
             if world > 1:
                 be.synchronize()
                 t0 = time.perf_counter()
@@ -145,12 +153,18 @@ def build_layers(be, pkg, synth, shapes, rank, world):
                 be.synchronize()
                 t_bcast += time.perf_counter() - t0
                 if rank != 0:
+                    t0 = time.perf_counter()
                     plan.set_csr(*got)
+                    be.synchronize()
+                    setup["receive_ms"].append((time.perf_counter() - t0) * 1e3)
+            if hasattr(plan, "stat"):
+                setup["code_bytes"] += plan.stat("code_bytes")
+                setup["device_bytes"] += plan.stat("device_bytes")
             bias = synth.bias_vector(s, 2000 + 31 * lid)
             bias = torch.from_numpy(bias).to(be.device) if bias is not None else None
             layers.append((s, plan, bias, si, lid))
             lid += 1
-    return layers, t_bcast
+    return layers, t_bcast, setup
 
 
 def last_layer_of_shape(layers):
@@ -405,7 +419,7 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         g0_of_rank = [r * per_gpu_batch for r in range(world)]
     global_batch = sum(per_rank)
 
-    layers, t_bcast = build_layers(be, pkg, synth, shapes, rank, world)
+    layers, t_bcast, setup = build_layers(be, pkg, synth, shapes, rank, world)
 
     # ---- synthetic activations resident in HBM (image k seeded by its GLOBAL index) -----------
     # Every LAYER has its own bottom / top pair (layers of one shape get copies of the same
@@ -452,23 +466,33 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     n_sampled = min(10, max(2, args.steps // 10)) if args.steps >= 4 else 1
     stride = max(1, args.steps // n_sampled)
     sampled = [k for k in range(args.steps) if k % stride == 0][:n_sampled]
-    step_ev = [be.event() for _ in range(args.steps + 1)]
-    ev = {k: [step_ev[k]] + [be.event() for _ in range(len(layers))] for k in sampled}
-    if world > 1:
-        dist.barrier()
-    be.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step_ev[k].record()
-        step(ev.get(k))
-    step_ev[args.steps].record()
-    be.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([elapsed], device=be.device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # R timed regions (--repeats, SURVEY 8d: median of >= 5 repeats), each EXACTLY K steps bracketed by a
+    # barrier + device synchronisation on both sides and reduced with MAX over the ranks; `value` is
+    # computed from the median region, the line also carries the fastest and the slowest one.
+    regions = []          # (elapsed seconds, step events, per-launch events of the sampled steps)
+    for rep in range(max(1, args.repeats)):
+        step_ev = [be.event() for _ in range(args.steps + 1)]
+        ev = {k: [step_ev[k]] + [be.event() for _ in range(len(layers))] for k in sampled}
+        if world > 1:
+            dist.barrier()
+        be.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step_ev[k].record()
+            step(ev.get(k))
+        step_ev[args.steps].record()
+        be.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([elapsed], device=be.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        regions.append((elapsed, step_ev, ev))
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    median_region = order[(len(order) - 1) // 2]     # (lower median for an even count: a region that was run)
+    elapsed, step_ev, ev = regions[median_region]
+    region_ms = [r[0] / args.steps * 1e3 for r in regions]
 
     # ---- self-check of what was just computed (outside the timed region) ----------------------
     oracle = oracle_loader()
@@ -478,6 +502,12 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         parity = float(t.item())
     cross = cross_rank_check(be, dist, synth, layers, shapes, tops, rank, world, g0_of_rank, per_rank)
+    receive = None
+    if world > 1:
+        # the slowest receiver's set_csr total and its slowest layer (rank 0 has none: it aligned)
+        t = torch.tensor([sum(setup["receive_ms"]), max(setup["receive_ms"] or [0.0])], device=be.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        receive = {"total": round(float(t[0].item()), 2), "max_per_layer": round(float(t[1].item()), 2)}
     if rank != 0:
         return None
 
@@ -491,8 +521,10 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     # event, add up to this much more than a step without them takes (so the corrected ones add up to it)
     ms_launches = float(np.mean([ev[k][0].elapsed_time(ev[k][len(layers)]) for k in sampled]))
     event_ms = max(0.0, (ms_launches - ms_plain) / len(layers)) if plain else 0.0
+    layer_ms_raw = []
     for li, (s, plan, bias, si, lid) in enumerate(layers):
         ms = [ev[k][li].elapsed_time(ev[k][li + 1]) for k in sampled]
+        layer_ms_raw.append(float(np.mean(ms)))
         m = max(float(np.mean(ms)) - event_ms, 1e-6)
         layer_ms.append(m)
         # the tiled kernel has a second instantiation for layers whose plane DMA can be issued from
@@ -509,14 +541,18 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         i["launches"] += 1
     per_layer, seen = [], {}
     layer_traffic = traffic_per_layer(args.workload)
+    seen_raw = {}
     for li, (s, plan, bias, si, lid) in enumerate(layers):
         seen.setdefault(si, []).append(layer_ms[li])
+        seen_raw.setdefault(si, []).append(layer_ms_raw[li])
     for si, s in enumerate(shapes):
         m = float(np.mean(seen[si]))
         name = layers[last_layer_of_shape(layers)[si]][1].kernel_name
         byt, flo = synth.algorithmic_bytes(s, per_gpu_batch), synth.flops(s, per_gpu_batch)
         t_hbm, t_fma = byt / (HBM_PEAK_GBS * 1e9), flo / (FP32_VECTOR_TFLOPS * 1e12)
         per_layer.append({"layer": s.name, "count": s.count, "us": round(m * 1e3, 1),
+                          # event to event, nothing taken off (one event between two launches costs `event_us`)
+                          "us_raw": round(float(np.mean(seen_raw[si])) * 1e3, 1),
                           "alg_GBps": round(byt / m / 1e6, 1), "sparse_TFLOPs": round(flo / m / 1e9, 2),
                           "hbm_frac": round(t_hbm / (m * 1e-3), 4), "fma_frac": round(t_fma / (m * 1e-3), 4),
                           "binding_frac": round(max(t_hbm, t_fma) / (m * 1e-3), 4),
@@ -570,6 +606,10 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
         "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        # R timed regions of K steps each; value / ms_per_step are the MEDIAN region's
+        "repeats": len(regions), "ms_per_step_min": round(min(region_ms), 4),
+        "ms_per_step_max": round(max(region_ms), 4),
+        "ms_per_step_regions": [round(v, 4) for v in region_ms],
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s @%d%% sparsity, batch %d/GPU, fp32" %
@@ -579,6 +619,14 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
                    "parallelism": "batch-sharded x%d" % world,
                    "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None},
         "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None,
+        # one-time costs outside the timed region (the reference's WeightAlign runs once per weight load,
+        # net.cpp:819): rank 0's WeightAlign per layer -- it now generates and assembles code --, the
+        # generated code's size, and (N > 1) what a RECEIVER spends in set_csr after the broadcast
+        "weight_align_ms": {"total": round(sum(setup["align_ms"]), 2),
+                            "max_per_layer": round(max(setup["align_ms"]), 2) if setup["align_ms"] else None,
+                            "layers": len(setup["align_ms"])},
+        "generated_code_bytes": setup["code_bytes"], "plan_device_bytes": setup["device_bytes"],
+        "weight_receive_ms": receive,
         "backend": be.name, "dist_backend": (be.dist_backend if test_be(be) else args.dist_backend) if world > 1 else None,
         "buffers": "one bottom/top pair per layer (no launch re-reads the previous launch's input)",
         "parity_max_rel_err": float("%.3g" % parity),
@@ -599,6 +647,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per workload, see DEFAULT_STEPS)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: per workload)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each; value = the median region (SURVEY 8d)")
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="run the step untimed for this long before the warm-up steps (clock settling; 0: not at all)")
     ap.add_argument("--workload", default="resnet50")
@@ -634,7 +684,7 @@ def _free_port():
     return port
 
 
-def launch_ranks(n_ranks, argv):
+def launch_ranks(n_ranks, argv, script=None):
     """`python bench.py --gpus N` with no RANK / WORLD_SIZE in the environment: start the N ranks.
 
     The reference's one command starts a worker per GPU itself (tools/caffe.cpp:254-256 ->
@@ -649,7 +699,7 @@ def launch_ranks(n_ranks, argv):
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+           "--master-port", str(_free_port()), script or os.path.abspath(__file__)] + list(argv)
     log("bench.py: starting %d ranks: %s" % (n_ranks, " ".join(cmd)))
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
     line = None
@@ -672,22 +722,14 @@ def launch_ranks(n_ranks, argv):
     return rc if rc >= 0 else 128 - rc
 
 
-def load_test_backend(path, local_rank):
-    """ESCOIN_BENCH_TEST_BACKEND=<file.py>: tests only (tests/bench_stub_backend.py) -- lets the CPU
-    suite run THIS file's launcher, rendezvous and reporting as one command on a box without a GPU.
-    The bench line of such a run says so (`backend`, `test_backend`) and is not a measurement."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("escoin_bench_test_backend", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod.make_backend(local_rank)
-
-
-def main():
+def main(backend_factory=None, script=None):
+    """backend_factory / script: the CPU test-suite's entry (tests/bench_stub_main.py) passes a stub
+    backend and its own path, so that launcher, rendezvous and reporting run on a box without a GPU;
+    `python bench.py` itself knows one backend, the HIP library."""
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # nothing below runs in the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], script))      # nothing below runs in the launcher
     # the host's CPU share is read BEFORE any OpenMP runtime exists: with OMP_PROC_BIND set, the
     # runtime torch loads pins this thread to one core and the affinity mask then reads "2 threads"
     global _HOST_INFO
@@ -706,9 +748,8 @@ def main():
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     kernel = {"auto": pkg.KERNEL_AUTO, "generic": pkg.KERNEL_GENERIC, "tiled": pkg.KERNEL_TILED,
               "jit": pkg.KERNEL_JIT}[args.kernel]
-    test_backend = os.environ.get("ESCOIN_BENCH_TEST_BACKEND")
-    if test_backend:
-        be = load_test_backend(test_backend, local_rank)
+    if backend_factory is not None:
+        be = backend_factory(local_rank)
         args.dist_backend = be.dist_backend
     else:
         be = HipBackend(pkg, local_rank, kernel, stream_stores=args.stream_stores)
@@ -720,7 +761,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     out = run(args, be, pkg, synth, ge.load_oracle, dist if world > 1 else None)
     if out is not None:
-        if test_backend:
+        if backend_factory is not None:
             out["test_backend"] = True
         print(json.dumps(out), flush=True)
     if world > 1:

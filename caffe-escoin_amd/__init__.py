@@ -30,6 +30,7 @@ API_SYMBOLS = [
     "escoin_plan_create", "escoin_plan_destroy", "escoin_plan_set_option",
     "escoin_weight_align", "escoin_plan_set_csr", "escoin_plan_nnz", "escoin_plan_get_csr",
     "escoin_plan_workspace_bytes", "escoin_plan_kernel_name", "escoin_plan_tiling_info", "escoin_forward",
+    "escoin_plan_export_aligned", "escoin_plan_import_aligned", "escoin_plan_stat",
     "escoin_gpu_sconv", "escoin_gpu_stretch", "escoin_copy_input_data",
     "escoin_gpu_sparse_dense2csr", "escoin_gpu_sparse_csrmm",
 ]
@@ -104,6 +105,12 @@ def lib():
     L.escoin_plan_tiling_info.argtypes = [vp]
     L.escoin_forward.restype = ip
     L.escoin_forward.argtypes = [vp, vp, vp, vp, ip, vp]
+    L.escoin_plan_export_aligned.restype = ip
+    L.escoin_plan_export_aligned.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.escoin_plan_import_aligned.restype = ip
+    L.escoin_plan_import_aligned.argtypes = [vp, vp, C.c_size_t, vp]
+    L.escoin_plan_stat.restype = C.c_long
+    L.escoin_plan_stat.argtypes = [vp, cp]
     L.escoin_gpu_sconv.restype = ip
     L.escoin_gpu_sconv.argtypes = [ip, ip, vp, ip, vp, vp, vp, vp] + [ip] * 10 + [vp, ip, ip, vp]
     L.escoin_gpu_stretch.restype = ip
@@ -203,6 +210,31 @@ class Plan(object):
                                         int(stretched)), "escoin_plan_get_csr")
         ng = np.array([self.nnz(g) for g in range(d.group)], np.int32)
         return rp, ci[:nnz], va[:nnz], ng
+
+    def export_aligned(self):
+        """The aligned form (CSR + channel deal + unit table + code object) as a numpy uint8 array."""
+        n = C.c_size_t()
+        check(lib().escoin_plan_export_aligned(self._h, None, 0, C.byref(n)), "escoin_plan_export_aligned")
+        buf = np.zeros(n.value, np.uint8)
+        check(lib().escoin_plan_export_aligned(self._h, _np_ptr(buf), buf.size, C.byref(n)),
+              "escoin_plan_export_aligned")
+        return buf[:n.value]
+
+    def import_aligned(self, blob, stream=None):
+        """Restore what export_aligned wrote; True when the persisted code object was loaded as it was."""
+        b = np.ascontiguousarray(blob, np.uint8)
+        check(lib().escoin_plan_import_aligned(self._h, _np_ptr(b), b.size, stream), "escoin_plan_import_aligned")
+        return self.stat("import_fast") == 1
+
+    def stat(self, key):
+        v = lib().escoin_plan_stat(self._h, key.encode())
+        if v < 0:
+            check(int(v), "escoin_plan_stat(%s)" % key)
+        return int(v)
+
+    @property
+    def align_ms(self):
+        return self.stat("align_us") * 1e-3
 
     @property
     def workspace_bytes(self):

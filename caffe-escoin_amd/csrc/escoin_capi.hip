@@ -2,6 +2,7 @@
 // plan life cycle, WeightAlign (dense -> CSR -> device weight streams), dispatch.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,12 @@ int fail(int code, const std::string &msg) {
 // Density above which KERNEL_AUTO sends a conv group to the dense fp32-MFMA kernel: the measured
 // crossover between the tiled sparse kernel and the dense kernel (profiles/r02_crossover.md).
 constexpr int kDefaultDenseThresholdPct = 50;
+
+static double ms_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int set_csr_host(escoin_plan *p, const int *rowptr, const int *colidx, const float *values, const int *nnz_per_group);
 
 static int out_dim(int in, int k, int pad, int stride, int dil) {
   // conv_layer.cpp:16-19
@@ -59,12 +66,7 @@ static void free_device(escoin_plan *p) {
   if (p->d_rowptr) (void)hipFree(p->d_rowptr);
   if (p->d_taps) (void)hipFree(p->d_taps);
   if (p->d_vals) (void)hipFree(p->d_vals);
-  if (p->d_stream) (void)hipFree(p->d_stream);
-  if (p->d_unit_hdr) (void)hipFree(p->d_unit_hdr);
-  p->d_unit_hdr = nullptr;
-  if (p->d_chan) (void)hipFree(p->d_chan);
-  p->d_chan = nullptr;
-  jit_unload(&p->jit_module);
+  tiled_release(p);
   if (p->d_col) (void)hipFree(p->d_col);
   p->d_col = nullptr;
   p->col_bytes = 0;
@@ -74,13 +76,14 @@ static void free_device(escoin_plan *p) {
   p->d_ktab = nullptr;
   p->d_rowptr = p->d_taps = nullptr;
   p->d_vals = nullptr;
-  p->d_stream = nullptr;
   p->device_bytes = 0;
 }
 
 // Uploads the CSR held in p->rowptr/colidx/values and builds the kernel-specific
 // streams.  Shared tail of escoin_weight_align and escoin_plan_set_csr.
-static int upload(escoin_plan *p, hipStream_t stream) {
+//   jit_blob: the generated-code section of a persisted aligned form (escoin_plan_import_aligned), tried
+//   where the generator would otherwise run.
+static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nullptr, size_t jit_blob_bytes = 0) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(ESCOIN_ENODEVICE, "no HIP device: this library has no CPU fallback");
@@ -199,11 +202,29 @@ static int upload(escoin_plan *p, hipStream_t stream) {
     const bool try_jit = p->kernel_choice == ESCOIN_KERNEL_JIT ||
                          (p->kernel_choice == ESCOIN_KERNEL_AUTO && jit_available() && sparse_enough);
     int rc = ESCOIN_OK;
-    if (try_jit) {
+    p->import_fast = false;
+    if (try_jit && jit_blob && jit_blob_bytes > 0) {
+      rc = tiled_import(p, jit_blob, jit_blob_bytes, stream);     // (leaves tiled.enabled false when the blob does not fit)
+      if (rc != ESCOIN_OK) return rc;
+      p->import_fast = p->tiled.enabled;
+    }
+    if (try_jit && !p->tiled.enabled) {
       rc = tiled_build(p, stream, true);
       if (rc != ESCOIN_OK && p->kernel_choice == ESCOIN_KERNEL_JIT) return rc;
       if (!p->tiled.enabled && p->kernel_choice == ESCOIN_KERNEL_JIT)
         return fail(ESCOIN_EINVAL, "generated-code kernel requested but the layer does not fit it");
+      if (rc != ESCOIN_OK) {
+        // KERNEL_AUTO: a failure of the code path (code object manager, module load, an allocation)
+        // is not the layer's failure -- the stream kernel runs it.  Whatever the attempt left on the
+        // device is released first, and the reason is not lost.
+        if (getenv("ESCOIN_VERBOSE"))
+          fprintf(stderr, "[escoin] generated code unavailable for this layer (%s): falling back to the stream kernel\n",
+                  g_last_error.c_str());
+        const float dens = p->tiled.density;
+        tiled_release(p);
+        p->tiled.density = dens;
+        rc = ESCOIN_OK;
+      }
     }
     if (!p->tiled.enabled) {
       rc = tiled_build(p, stream, false);   // leaves tiled.enabled false when the stream does not fit LDS
@@ -320,6 +341,7 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
 
 int escoin_weight_align(escoin_plan *p, const float *dense_w, int w_on_device, void *stream) {
   if (!p || !dense_w) return fail(ESCOIN_EINVAL, "null argument");
+  const auto t_start = std::chrono::steady_clock::now();
   const Geometry &g = p->g;
   const size_t count = (size_t)g.d.M * g.kdim;
   std::vector<float> host;
@@ -356,11 +378,27 @@ int escoin_weight_align(escoin_plan *p, const float *dense_w, int w_on_device, v
     }
   }
   p->aligned = false;
-  return upload(p, (hipStream_t)stream);
+  const int rc = upload(p, (hipStream_t)stream);
+  p->align_ms = ms_since(t_start);
+  return rc;
 }
 
 int escoin_plan_set_csr(escoin_plan *p, const int *rowptr, const int *colidx, const float *values,
                         const int *nnz_per_group, void *stream) {
+  const auto t_start = std::chrono::steady_clock::now();
+  const int rc = set_csr_host(p, rowptr, colidx, values, nnz_per_group);
+  if (rc != ESCOIN_OK) return rc;
+  p->aligned = false;
+  const int rc2 = upload(p, (hipStream_t)stream);
+  p->align_ms = ms_since(t_start);
+  return rc2;
+}
+
+}  // extern "C"
+
+namespace escoin {
+// Validates a CSR and copies it into the plan's host vectors (shared by set_csr and import_aligned).
+int set_csr_host(escoin_plan *p, const int *rowptr, const int *colidx, const float *values, const int *nnz_per_group) {
   if (!p || !rowptr || !nnz_per_group) return fail(ESCOIN_EINVAL, "null argument");
   const Geometry &g = p->g;
   long base = 0;
@@ -387,8 +425,104 @@ int escoin_plan_set_csr(escoin_plan *p, const int *rowptr, const int *colidx, co
     p->values[grp].assign(values + base, values + base + n_g);
     base += n_g;
   }
+  return ESCOIN_OK;
+}
+}  // namespace escoin
+
+extern "C" {
+
+// ---- the persisted aligned form -----------------------------------------------------------------
+// [AlignedHdr][desc][nnz_per_group][rowptr][colidx][values][generated-code section (sconv_tiled.hip)]
+namespace {
+constexpr uint32_t kAlignedMagic = 0x4E474C41u;   // "ALGN"
+struct AlignedHdr {
+  uint32_t magic, version;
+  uint64_t total_bytes, nnz, jit_bytes;
+};
+}  // namespace
+
+int escoin_plan_export_aligned(const escoin_plan *p, void *buf, size_t capacity, size_t *bytes) {
+  if (!p || !bytes) return fail(ESCOIN_EINVAL, "null argument");
+  if (!p->aligned) return fail(ESCOIN_ESTATE, "export_aligned before weight_align / set_csr");
+  const Geometry &g = p->g;
+  std::vector<char> jit;
+  const int rc = tiled_export(p, &jit);
+  if (rc != ESCOIN_OK) return rc;
+  uint64_t nnz = 0;
+  for (const auto &c : p->colidx) nnz += c.size();
+  const size_t need = sizeof(AlignedHdr) + sizeof(escoin_conv_desc) + 4 * (size_t)g.d.group +
+                      4 * (size_t)g.d.group * (g.Mg + 1) + 8 * (size_t)nnz + jit.size();
+  *bytes = need;
+  if (!buf) return ESCOIN_OK;                       // size query
+  if (capacity < need) return fail(ESCOIN_EINVAL, "export_aligned: buffer too small");
+  char *q = static_cast<char *>(buf);
+  AlignedHdr h{kAlignedMagic, 1u, (uint64_t)need, nnz, (uint64_t)jit.size()};
+  memcpy(q, &h, sizeof(h)); q += sizeof(h);
+  memcpy(q, &g.d, sizeof(g.d)); q += sizeof(g.d);
+  for (int grp = 0; grp < g.d.group; ++grp) { const int n = (int)p->colidx[grp].size(); memcpy(q, &n, 4); q += 4; }
+  for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->rowptr[grp].data(), 4 * (size_t)(g.Mg + 1)); q += 4 * (size_t)(g.Mg + 1); }
+  for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->colidx[grp].data(), 4 * p->colidx[grp].size()); q += 4 * p->colidx[grp].size(); }
+  for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->values[grp].data(), 4 * p->values[grp].size()); q += 4 * p->values[grp].size(); }
+  if (!jit.empty()) memcpy(q, jit.data(), jit.size());
+  return ESCOIN_OK;
+}
+
+int escoin_plan_import_aligned(escoin_plan *p, const void *buf, size_t bytes, void *stream) {
+  if (!p || !buf) return fail(ESCOIN_EINVAL, "null argument");
+  const auto t_start = std::chrono::steady_clock::now();
+  const Geometry &g = p->g;
+  AlignedHdr h;
+  if (bytes < sizeof(h) + sizeof(escoin_conv_desc)) return fail(ESCOIN_EINVAL, "import_aligned: truncated blob");
+  const char *q = static_cast<const char *>(buf);
+  memcpy(&h, q, sizeof(h)); q += sizeof(h);
+  if (h.magic != kAlignedMagic || h.version != 1u || h.total_bytes != bytes)
+    return fail(ESCOIN_EINVAL, "import_aligned: not an aligned-form blob of this library");
+  escoin_conv_desc d;
+  memcpy(&d, q, sizeof(d)); q += sizeof(d);
+  // the weights' own geometry must match; batch, bias and ReLU are the importing plan's business
+  if (d.C != g.d.C || d.M != g.d.M || d.KH != g.d.KH || d.KW != g.d.KW || d.group != g.d.group)
+    return fail(ESCOIN_EINVAL, "import_aligned: the blob was exported for other weights (C / M / kernel / group differ)");
+  const size_t csr_bytes = 4 * (size_t)g.d.group + 4 * (size_t)g.d.group * (g.Mg + 1) + 8 * (size_t)h.nnz;
+  if (sizeof(h) + sizeof(d) + csr_bytes + h.jit_bytes != bytes) return fail(ESCOIN_EINVAL, "import_aligned: section sizes do not add up");
+  std::vector<int> ng(g.d.group), rp((size_t)g.d.group * (g.Mg + 1)), ci((size_t)h.nnz);
+  std::vector<float> va((size_t)h.nnz);
+  memcpy(ng.data(), q, 4 * ng.size()); q += 4 * ng.size();
+  memcpy(rp.data(), q, 4 * rp.size()); q += 4 * rp.size();
+  memcpy(ci.data(), q, 4 * ci.size()); q += 4 * ci.size();
+  memcpy(va.data(), q, 4 * va.size()); q += 4 * va.size();
+  uint64_t sum = 0;
+  for (int n : ng) sum += (uint64_t)std::max(0, n);
+  if (sum != h.nnz) return fail(ESCOIN_EINVAL, "import_aligned: nnz_per_group does not match the blob's nnz");
+  const int rc = set_csr_host(p, rp.data(), ci.data(), va.data(), ng.data());
+  if (rc != ESCOIN_OK) return rc;
   p->aligned = false;
-  return upload(p, (hipStream_t)stream);
+  // the code section only counts for the geometry it was generated for (the LDS offsets in the code
+  // are this H x W's) and for the same epilogue flags
+  const bool same_geom = d.H == g.d.H && d.W == g.d.W && d.pad_h == g.d.pad_h && d.pad_w == g.d.pad_w &&
+                         d.stride_h == g.d.stride_h && d.stride_w == g.d.stride_w && d.dil_h == g.d.dil_h &&
+                         d.dil_w == g.d.dil_w && d.N == g.d.N;
+  const int rc2 = upload(p, (hipStream_t)stream, same_geom && h.jit_bytes ? q : nullptr, same_geom ? (size_t)h.jit_bytes : 0);
+  p->align_ms = ms_since(t_start);
+  return rc2;
+}
+
+long escoin_plan_stat(const escoin_plan *p, const char *key) {
+  if (!p || !key) return fail(ESCOIN_EINVAL, "null argument");
+  if (!strcmp(key, "align_us")) return (long)(p->align_ms * 1e3);
+  if (!strcmp(key, "code_bytes")) return (long)(p->tiled.enabled && p->tiled.jit ? p->jit_module.code_bytes : 0);
+  if (!strcmp(key, "device_bytes")) return (long)p->device_bytes;
+  if (!strcmp(key, "import_fast")) return p->import_fast ? 1 : 0;
+  if (!strcmp(key, "jit_rows")) return p->tiled.jit ? p->tiled.jit_rows : 0;
+  if (!strcmp(key, "jit_records")) return p->tiled.jit ? p->tiled.jit_records : 0;
+  if (!strcmp(key, "lds_bytes")) return p->tiled.enabled ? (long)p->tiled.lds_bytes : 0;
+  if (!strcmp(key, "workgroup_columns")) return p->tiled.enabled ? p->tiled.tiling.n_ocblk : 0;
+  if (!strcmp(key, "kernel_choice")) {
+    if (!p->aligned) return fail(ESCOIN_ESTATE, "kernel_choice before weight_align / set_csr");
+    if (p->use_dense) return ESCOIN_KERNEL_DENSE;
+    if (!p->tiled.enabled) return ESCOIN_KERNEL_GENERIC;
+    return p->tiled.jit ? ESCOIN_KERNEL_JIT : ESCOIN_KERNEL_TILED;
+  }
+  return fail(ESCOIN_EINVAL, std::string("unknown stat: ") + key);
 }
 
 long escoin_plan_nnz(const escoin_plan *p, int group) {

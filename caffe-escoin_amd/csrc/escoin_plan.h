@@ -91,6 +91,13 @@ struct escoin_plan {
   escoin::JitModule jit_module;   // generated-code kernel: the loaded code object and where its code lives
   unsigned *d_chan = nullptr;     // slot -> output channel (WeightStream::chan)
   size_t stream_words = 0;
+  size_t tiled_device_bytes = 0;  // device bytes of the five members above (part of device_bytes)
+  // host copies of what a generated-code plan loaded, kept for escoin_plan_export_aligned: the code
+  // object (ELF), the unit table and the channel deal
+  std::vector<char> jit_elf;
+  std::vector<uint32_t> h_unit_off, h_chan;
+  double align_ms = 0.0;          // wall time of the last weight_align / set_csr / import_aligned
+  bool import_fast = false;       // the last import_aligned loaded a persisted code object as it was
 
   // dense fallback (fp32 MFMA implicit GEMM), chosen per conv group: bit g of dense_mask = group g
   // goes to the MFMA kernel, bit g of sparse_mask = to the sparse kernels (layers with more than 64
@@ -121,6 +128,12 @@ const char *generic_kernel_name(bool relu);
 // sconv_tiled.hip
 bool tiled_supported(const Geometry &g);
 int tiled_build(escoin_plan *p, hipStream_t stream, bool jit);  // fills p->tiled, uploads streams / loads generated code
+void tiled_release(escoin_plan *p);   // frees what tiled_build put on the device (and its share of device_bytes)
+// The fast half of escoin_plan_import_aligned: a generated-code plan restored from what
+// escoin_plan_export_aligned wrote (tiling, channel deal, unit table, code object) -- no channel
+// deal, no generator pass, no assembler.  `blob` points behind the CSR section.
+int tiled_export(const escoin_plan *p, std::vector<char> *out);
+int tiled_import(escoin_plan *p, const char *blob, size_t bytes, hipStream_t stream);
 int launch_tiled(const escoin_plan *p, const float *bottom, const float *bias, float *top,
                  int n_images, hipStream_t stream);
 const char *tiled_kernel_name(const escoin_plan *p);

@@ -153,29 +153,18 @@ bool jit_available() {
   return on;
 }
 
-int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream) {
-  if (code.empty()) return fail(ESCOIN_EINVAL, "jit: empty program");
-  // the bytes reach the assembler through .incbin: a file, gone again before this returns
-  const char *tmpdir = getenv("TMPDIR");
-  std::string path = std::string(tmpdir && *tmpdir ? tmpdir : "/tmp") + "/escoin_jit_XXXXXX";
-  std::vector<char> pbuf(path.begin(), path.end());
-  pbuf.push_back(0);
-  const int fd = mkstemp(pbuf.data());
-  if (fd < 0) return fail(ESCOIN_ENOMEM, "jit: cannot create a temporary file in " + path);
-  const size_t bytes = code.size() * 4;
-  size_t done = 0;
-  while (done < bytes) {
-    const ssize_t n = write(fd, reinterpret_cast<const char *>(code.data()) + done, bytes - done);
-    if (n <= 0) break;
-    done += (size_t)n;
-  }
-  close(fd);
-  std::string src = kWrapper;
-  src.replace(src.find("%BLOB%"), 6, pbuf.data());
-  std::vector<char> elf;
-  const std::string err = done == bytes ? assemble_and_link(src, &elf) : std::string("short write to the temporary file");
-  unlink(pbuf.data());
-  if (!err.empty()) return fail(ESCOIN_EHIP, "jit: " + err);
+// Where the blob's temporary file goes: $TMPDIR unless it holds a character the assembler's string
+// syntax would need escaped (the path is spliced into an .incbin directive).
+static std::string tmp_dir() {
+  const char *t = getenv("TMPDIR");
+  if (!t || !*t) return "/tmp";
+  for (const char *c = t; *c; ++c)
+    if (*c == '"' || *c == '\\' || *c == '\n' || *c == '\r') return "/tmp";
+  return t;
+}
+
+int jit_load_elf(const std::vector<char> &elf, size_t code_bytes, JitModule *out, hipStream_t stream) {
+  if (elf.size() < 64 || std::memcmp(elf.data(), "\177ELF", 4) != 0) return fail(ESCOIN_EINVAL, "jit: not a code object");
   JitModule m;
   ESCOIN_HIP_TRY(hipModuleLoadData(&m.module, elf.data()));
   hipFunction_t locator = nullptr;
@@ -196,9 +185,36 @@ int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stre
     return fail(ESCOIN_EHIP, std::string("jit: locating the generated code failed: ") + hipGetErrorString(e));
   }
   m.code_base = addr;
-  m.code_bytes = bytes;
+  m.code_bytes = code_bytes;
   *out = m;
   return ESCOIN_OK;
+}
+
+int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream, std::vector<char> *keep_elf) {
+  if (code.empty()) return fail(ESCOIN_EINVAL, "jit: empty program");
+  // the bytes reach the assembler through .incbin: a file, gone again before this returns
+  std::string path = tmp_dir() + "/escoin_jit_XXXXXX";
+  std::vector<char> pbuf(path.begin(), path.end());
+  pbuf.push_back(0);
+  const int fd = mkstemp(pbuf.data());
+  if (fd < 0) return fail(ESCOIN_ENOMEM, "jit: cannot create a temporary file in " + path);
+  const size_t bytes = code.size() * 4;
+  size_t done = 0;
+  while (done < bytes) {
+    const ssize_t n = write(fd, reinterpret_cast<const char *>(code.data()) + done, bytes - done);
+    if (n <= 0) break;
+    done += (size_t)n;
+  }
+  close(fd);
+  std::string src = kWrapper;
+  src.replace(src.find("%BLOB%"), 6, pbuf.data());
+  std::vector<char> elf;
+  const std::string err = done == bytes ? assemble_and_link(src, &elf) : std::string("short write to the temporary file");
+  unlink(pbuf.data());
+  if (!err.empty()) return fail(ESCOIN_EHIP, "jit: " + err);
+  const int rc = jit_load_elf(elf, bytes, out, stream);
+  if (rc == ESCOIN_OK && keep_elf) keep_elf->swap(elf);
+  return rc;
 }
 
 void jit_unload(JitModule *m) {

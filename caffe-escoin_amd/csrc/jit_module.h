@@ -15,15 +15,20 @@ struct JitModule {
   size_t code_bytes = 0;
 };
 
-// False when generated code cannot be used in this process (ESCOIN_JIT=0, or the code object
-// manager cannot be reached); the LDS-staged stream kernel is then what KERNEL_AUTO picks.
+// False when generated code is switched off in this process (ESCOIN_JIT=0); the LDS-staged stream
+// kernel is then what KERNEL_AUTO picks.  (The library links libamd_comgr, a part of every ROCm
+// install and what the HIP runtime itself loads kernels with; a failure inside it at WeightAlign
+// makes KERNEL_AUTO fall back to the stream kernel with a message under ESCOIN_VERBOSE.)
 bool jit_available();
 
 // Wraps `code` (jit_codegen.h) in a code object -- a three-line assembly file that .incbin's the
 // bytes behind a locator kernel, assembled and linked in process by the ROCm code object manager
 // (libamd_comgr, the library the HIP runtime itself loads kernels with) -- loads it on the
 // current device and asks the locator where the code landed.  ESCOIN_* status.
-int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream);
+// keep_elf != nullptr: the code object's bytes are handed back (escoin_plan_export_aligned persists them).
+int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream, std::vector<char> *keep_elf = nullptr);
+// Loads a code object jit_load produced earlier (same library build, same target): no assembler run.
+int jit_load_elf(const std::vector<char> &elf, size_t code_bytes, JitModule *out, hipStream_t stream);
 void jit_unload(JitModule *m);
 
 }  // namespace escoin

@@ -66,7 +66,9 @@ extern "C" {
 #define ESCOIN_KERNEL_DENSE 3   /* implicit-GEMM on the fp32 matrix cores (MFMA)  */
 #define ESCOIN_KERNEL_JIT 4     /* LDS-staged tiles; the weight walk is machine code
                                    WeightAlign generated from the sparsity pattern
-                                   (what AUTO picks for stride-1 layers)            */
+                                   (AUTO picks it per plan from what WeightAlign knows:
+                                   code bytes against the L2 of an XCD, nonzeros per row;
+                                   escoin_capi.hip choose_walk)                       */
 
 /* Geometry of one ConvolutionLayer: what LayerSetUp/Reshape derive from
  * ConvolutionParameter + the bottom shape (base_conv_layer.cpp:276-530). */
@@ -152,8 +154,27 @@ ESCOIN_API long escoin_plan_nnz(const escoin_plan *plan, int group);
 ESCOIN_API int escoin_plan_get_csr(const escoin_plan *plan, int *rowptr, int *colidx, float *values,
                         int stretched);
 
-/* Device bytes owned by the plan (CSR + weight streams + scratch). */
+/* Device bytes owned by the plan (CSR + weight streams / generated code + scratch). */
 ESCOIN_API size_t escoin_plan_workspace_bytes(const escoin_plan *plan);
+
+/* The aligned form as one relocatable byte blob: the CSR and -- for a generated-code plan -- the
+ * channel deal, the unit table and the code object WeightAlign produced.  The reference recomputes
+ * its aligned form on every weight load (Net::CopyTrainedLayersFrom -> WeightAlign, net.cpp:819);
+ * here WeightAlign compiles code (5-165 ms per layer), so a deployment persists it once.
+ *   export: buf == NULL queries the size (*bytes); otherwise writes *bytes <= capacity bytes.
+ *   import: restores the CSR (always) and, when the blob's code section was written by this library
+ *           build for this geometry / batch / option set on a device with the same CU count, loads the
+ *           persisted code object as it is -- no channel deal, no generator pass, no assembler
+ *           (escoin_plan_stat(plan, "import_fast") == 1); otherwise it aligns from the CSR like
+ *           escoin_plan_set_csr.  Plan options must be set before the import, as before weight_align. */
+ESCOIN_API int escoin_plan_export_aligned(const escoin_plan *plan, void *buf, size_t capacity, size_t *bytes);
+ESCOIN_API int escoin_plan_import_aligned(escoin_plan *plan, const void *buf, size_t bytes, void *stream);
+
+/* Integer facts about an aligned plan (negative = error): "align_us" wall time of the last
+ * weight_align / set_csr / import_aligned, "code_bytes" generated machine code on the device,
+ * "device_bytes", "import_fast", "jit_rows", "jit_records", "lds_bytes", "workgroup_columns",
+ * "kernel_choice" (the ESCOIN_KERNEL_* id AUTO resolved to for the sparse groups). */
+ESCOIN_API long escoin_plan_stat(const escoin_plan *plan, const char *key);
 
 /* Name of the device kernel the plan launches (the symbol rocprofv3 reports). */
 ESCOIN_API const char *escoin_plan_kernel_name(const escoin_plan *plan);

@@ -1,8 +1,8 @@
 """Test-only backend for bench.py: the same surface as bench.HipBackend / caffe_escoin_amd.Plan with
 the arithmetic done by the CPU oracle, so that bench.py's launcher, rendezvous, sharding, broadcast,
 checks and reporting run on a box without a GPU (tests/test_bench_gloo.py, tests/test_bench_launcher.py).
-Loaded by bench.py only through ESCOIN_BENCH_TEST_BACKEND=<this file>; the bench line of such a run is
-marked `"test_backend": true` and is not a measurement."""
+bench.py itself cannot load it: tests/bench_stub_main.py (the tests' entry) passes it to bench.main();
+the bench line of such a run is marked `"test_backend": true` and is not a measurement."""
 import os
 import sys
 import time
@@ -34,6 +34,9 @@ class StubPlan(object):
     def weight_align(self, w):
         self.w = np.ascontiguousarray(w, np.float32)
 
+    def stat(self, key):
+        return 0
+
     def get_csr(self):
         s = self.s
         mg, cg = s.M // s.group, s.C // s.group
@@ -59,6 +62,16 @@ class StubPlan(object):
         s = self.s
         g = self.o.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
                         s.dil_h, s.dil_w, s.group)
+        n = x.shape[0]
+        if os.environ.get("ESCOIN_STUB_CHECKED_IMAGES_ONLY") == "1" and n > 3:
+            # full-size rehearsals (8 ranks x 256 images x 16 layers): only the images bench.py's two
+            # checks read (first, middle, last of a shard) are computed, the rest stay zero
+            idx = sorted(set([0, n // 2, n - 1]))
+            if top is None:
+                top = self.torch.zeros((n, s.M) + tuple(self.o.out_hw(g)), dtype=self.torch.float32)
+            y = self.o.conv_forward(g, x[idx].numpy(), self.w, None if bias is None else bias.numpy(), gate=False)
+            top[idx] = self.torch.from_numpy(y)
+            return top
         y = self.o.conv_forward(g, x.numpy(), self.w, None if bias is None else bias.numpy(), gate=False)
         y = self.torch.from_numpy(y)
         if top is not None:

@@ -2,23 +2,23 @@
 torch.distributed.run), never touches the GPU, relays rank 0's JSON line and the worst exit code --
 the counterpart of the reference's single `caffe` command starting a worker per GPU
 (tools/caffe.cpp:254-256, parallel.cpp:328-358).  Runs here on two gloo ranks with the test backend
-(tests/bench_stub_backend.py: forward by the oracle)."""
+(tests/bench_stub_main.py -> tests/bench_stub_backend.py: forward by the oracle; bench.py itself has no
+switch that could point it at the oracle)."""
 import json
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STUB = os.path.join(ROOT, "tests", "bench_stub_backend.py")
+STUB_MAIN = os.path.join(ROOT, "tests", "bench_stub_main.py")
 
 
 def _run_one_command(extra, env_extra=None, timeout=300):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    env["ESCOIN_BENCH_TEST_BACKEND"] = STUB
     env.update(env_extra or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, cwd=ROOT,
+    p = subprocess.run([sys.executable, STUB_MAIN] + extra, env=env, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
     return p.returncode, lines, p.stderr.decode()
@@ -44,6 +44,33 @@ def test_one_command_strong_scaling_global_batch():
     assert rc == 0, err[-2000:]
     out = json.loads(lines[-1])
     assert out["scaling"] == "strong" and out["config"]["global_batch"] == 5 and out["n_ranks_seen"] == 2
+
+
+def test_product_bench_has_no_test_backend_switch():
+    """a bench that an environment variable can point at the oracle is one variable away from
+    a fake number.  bench.py's own main() knows one backend."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "ESCOIN_BENCH_TEST_BACKEND" not in src and "import bench_stub" not in src
+    assert "getenv" not in src.split("def main(")[1] and "environ.get(\"ESCOIN" not in src.split("def main(")[1]
+
+
+def test_scale_command_line_eight_ranks_global_batch_2048():
+    """The driver's SCALE run at its largest point -- `bench.py --gpus 8 --global-batch 2048`, BASELINE
+    configs[3] -- end to end as one command: eight gloo ranks, 8 x 256-image shards of the ResNet-50 set,
+    one JSON line, n_ranks_seen 8 (the stub computes only the images the two checks read)."""
+    rc, lines, err = _run_one_command(["--gpus", "8", "--global-batch", "2048", "--steps", "1", "--warmup", "0",
+                                       "--repeats", "1", "--settle-ms", "0", "--no-cpu"],
+                                      env_extra={"ESCOIN_STUB_CHECKED_IMAGES_ONLY": "1", "OMP_NUM_THREADS": "1"},
+                                      timeout=900)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["n_ranks_seen"] == 8 and out["scaling"] == "strong"
+    assert out["config"]["global_batch"] == 2048 and "batch 256/GPU" in out["config"]["workload"]
+    assert out["config"]["layers_per_step"] == 16 and "ResNet-50" in out["config"]["workload"]
+    assert out["parity_max_rel_err"] <= 1e-4 and out["cross_rank_checksum_rel_diff"] <= 1e-5
+    assert out["weight_broadcast_ms"] is not None and out["weight_receive_ms"]["total"] >= 0
+    assert out["repeats"] == 1 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
 
 
 def test_launcher_relays_a_failing_rank():
