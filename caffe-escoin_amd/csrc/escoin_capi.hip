@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -24,6 +25,7 @@ int fail(int code, const std::string &msg) {
 // Density above which KERNEL_AUTO sends a conv group to the dense fp32-MFMA kernel: the measured
 // crossover between the tiled sparse kernel and the dense kernel (profiles/r02_crossover.md).
 constexpr int kDefaultDenseThresholdPct = 50;
+constexpr int kGenericDenseThresholdPct = 4;
 
 static double ms_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -135,10 +137,43 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
     if (p->dense_gate) {
       if ((double)p->colidx[0].size() / per_group > 0.2) dense.assign(G, 1);
     } else {
-      const double thr = (p->dense_threshold_pct >= 0 ? p->dense_threshold_pct : kDefaultDenseThresholdPct) / 100.0;
+      // a geometry the tiled kernels do not cover (stride / dilation != 1) has only the generic kernel on
+      // the sparse side -- one lane per output pixel, ~2 sparse TFLOP/s -- against 65-110 dense TFLOP/s:
+      // the MFMA kernel wins from ~4 % density on (ResNet-50's stride-2 1x1 layers pruned @90 %:
+      // 2.2-2.7 ms generic vs 0.17-0.58 ms dense, profiles/r04_chain_prune_1x1.md)
+      const bool fast_sparse = tiled_supported(g);
+      const int auto_thr = fast_sparse ? kDefaultDenseThresholdPct : kGenericDenseThresholdPct;
+      const double thr = (p->dense_threshold_pct >= 0 ? p->dense_threshold_pct : auto_thr) / 100.0;
+      // Above the cut the dense kernel used to win by rule.  With generated code on every sparse layer it
+      // does not: measured crossovers (profiles/r04_crossover.md) sit between 53 % density (AlexNet conv3, whose
+      // 507 output tiles fill the 512 MFMA slots exactly) and > 90 % (res2, 64 output channels: half-empty
+      // 64 x 128 tiles) -- no single density separates them, what WeightAlign knows about the two kernels does:
+      //   dense  = rounds of 128 x 128 (64 x 128 when a group has <= 64 channels) output tiles on 512 slots at
+      //            110 TFLOP/s (x 0.7 for the narrow tiles), no faster than the blobs at 4.0 TB/s;
+      //   sparse = 25 us + 2 * pixels * nonzeros at 68 TFLOP/s (3x3 / 5x5) or 58 (1x1), no faster than the
+      //            blobs at 4.8 TB/s.
+      // Worst regret over the 14 shapes x 12 sparsities of the table: 6.6 % (a fixed 50 % cut: 42 %).  The model
+      // only ever decides ABOVE the cut; below it the sparse kernel always won.  An explicit
+      // dense_threshold_pct option is obeyed as given.
+      auto model_says_dense = [&](long nnz_g) {
+        const double n = (double)(p->tiling_batch > 0 ? p->tiling_batch : g.d.N);
+        const double pix = n * g.OH * g.OW;
+        const int tm = g.Mg <= 64 ? 64 : 128;
+        const double tiles = std::ceil((double)g.Mg / tm) * std::ceil(pix / 128.0);
+        const double rounds = std::ceil(tiles / 512.0);
+        const double byt = 4.0 * n * ((double)g.Cg * g.d.H * g.d.W + (double)g.Mg * g.OH * g.OW);
+        const double t_dense = std::max(rounds * 2.0 * tm * 128.0 * g.kdim / (110e6 * (tm == 64 ? 0.7 : 1.0) / 512.0), byt / 4.0e6);
+        const double t_sparse = std::max(25.0 + 2.0 * pix * (double)nnz_g / (g.d.KH * g.d.KW > 1 ? 68e6 : 58e6), byt / 4.8e6 + 8.0);
+        return t_dense < t_sparse;
+      };
+      const bool use_model = p->dense_threshold_pct < 0 && fast_sparse && jit_available() &&
+                             !(getenv("ESCOIN_DENSE_MODEL") && atoi(getenv("ESCOIN_DENSE_MODEL")) == 0);
       if (G <= 64) {
-        for (int grp = 0; grp < G; ++grp) dense[grp] = (double)p->colidx[grp].size() / per_group > thr;
-      } else if ((double)nnz / (per_group * G) > thr) {
+        for (int grp = 0; grp < G; ++grp) {
+          const long n_g = (long)p->colidx[grp].size();
+          dense[grp] = (double)n_g / per_group > thr && (!use_model || model_says_dense(n_g));
+        }
+      } else if ((double)nnz / (per_group * G) > thr && (!use_model || model_says_dense(nnz / G))) {
         dense.assign(G, 1);
       }
     }
@@ -179,12 +214,15 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
   if (want_tiled) {
     if (!tiled_supported(g))
       return fail(ESCOIN_EINVAL, "tiled kernel requested for a geometry it does not support");
-    // AUTO: generated code (jit_codegen.h) for layers at least 82 % sparse, the LDS-staged stream
-    // above that density: measured on the ResNet-50 and AlexNet sets at 60-95 % sparsity (same-box
-    // A/B, profiles/r03_jit_vs_stream.md) generated code wins from 85 % on every layer (ResNet step
-    // -15 % at 90 %) and loses up to 15 % on AlexNet's 13 x 13 layers at 80 % and below, where one
-    // scalar move per nonzero is a larger share of the walk.  ESCOIN_JIT_MAX_DENSITY_PCT moves the cut.
-    static const int jit_max_density_pct = getenv("ESCOIN_JIT_MAX_DENSITY_PCT") ? atoi(getenv("ESCOIN_JIT_MAX_DENSITY_PCT")) : 18;
+    // AUTO: generated code (jit_codegen.h) wherever the sparse path runs.  Round 3 cut it off at 18 %
+    // density (25 % for layers of at most 100 k nonzeros) because AlexNet's 13 x 13 layers lost 9-14 % to
+    // the stream kernel at 80 % sparsity and below; that loss was the eight L2s each streaming every
+    // column's code, and grouping the workgroup columns by XCD (sconv_tiled.hip, xcd_q) removed it:
+    // over 50-95 % sparsity on every BASELINE 3x3 / 5x5 / 1x1 shape generated code is now ahead of the
+    // stream kernel at every point (profiles/r04_crossover.md; the worst point, alex_conv2 @50 %, by 14 %).
+    // ESCOIN_JIT_MAX_DENSITY_PCT restores a density cut for experiments; code beyond kMaxJitBytes
+    // (sconv_tiled.hip) falls back to the stream kernel by itself.
+    static const int jit_max_density_pct = getenv("ESCOIN_JIT_MAX_DENSITY_PCT") ? atoi(getenv("ESCOIN_JIT_MAX_DENSITY_PCT")) : 100;
     double dens_sparse = 0;
     long nz_sparse = 0;
     {
@@ -193,12 +231,7 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
         if (!dense[grp]) { nz_sparse += (long)p->colidx[grp].size(); ++ng; }
       dens_sparse = ng ? (double)nz_sparse / (per_group * ng) : 0.0;
     }
-    // ... and up to 25 % density where the whole layer's code stays under ~4 MB (40 bytes per nonzero: the
-    // L2 of an XCD holds it): AlexNet's conv2 / conv5 at 80 % sparsity run generated code 1-6 % faster than
-    // the stream, its conv3 / conv4 (7 and 5 MB of code) 9-14 % slower (profiles/r03_jit_vs_stream.md).
-    static const long jit_small_nnz = getenv("ESCOIN_JIT_SMALL_NNZ") ? atol(getenv("ESCOIN_JIT_SMALL_NNZ")) : 100000;
-    const bool sparse_enough = dens_sparse * 100.0 <= jit_max_density_pct ||
-                               (dens_sparse <= 0.25 && nz_sparse <= jit_small_nnz);
+    const bool sparse_enough = dens_sparse * 100.0 <= jit_max_density_pct;
     const bool try_jit = p->kernel_choice == ESCOIN_KERNEL_JIT ||
                          (p->kernel_choice == ESCOIN_KERNEL_AUTO && jit_available() && sparse_enough);
     int rc = ESCOIN_OK;

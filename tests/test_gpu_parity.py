@@ -99,9 +99,32 @@ def _config_sets(synth):
             ("resnet50", synth.resnet50_3x3(N=256)), ("googlenet", synth.googlenet_1x1(N=256))]
 
 
-def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None, kernel=None, relu=False):
+def _generic_reference(pkg, torch, s, seed, relu=False):
+    """The whole config batch through the generic kernel -- one lane per output pixel, the reference's
+    loop nest and summation order, BIT-EXACT to the oracle (test_config_layers_small_batch_vs_oracle and
+    the goldens assert that) -- on the same device-generated input _check_full_batch uses: the on-device
+    yardstick for all N images of a fast kernel's output."""
+    synth_mod = pkg.synth
+    dev = torch.device("cuda:0")
+    w, b = synth_mod.pruned_weights(s, seed), synth_mod.bias_vector(s, seed + 1)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=pkg.KERNEL_GENERIC)
+    plan.weight_align(w)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 2)
+    x = torch.rand((s.N, s.C, s.H, s.W), device=dev, generator=gen) * 2 - 1
+    top = plan.forward(x, torch.from_numpy(b).to(dev) if b is not None else None)
+    torch.cuda.synchronize()
+    assert "generic" in plan.kernel_name
+    plan.close()
+    return top
+
+
+def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None, kernel=None, relu=False,
+                      full_ref=None):
     """Forward of the WHOLE config batch on device-generated input; images {0, 1 and 3 (inside the
-    first multi-image tile), N/2, N-2, N-1} are checked against the oracle (<= 1e-4)."""
+    first multi-image tile), N/2, N-2, N-1} are checked against the oracle (<= 1e-4).  full_ref: the
+    generic kernel's output for the same input (_generic_reference): ALL N images are compared with it
+    on the device, same tolerance."""
     dev = torch.device("cuda:0")
     w, b = synth.pruned_weights(s, seed), synth.bias_vector(s, seed + 1)
     own = plan is None
@@ -113,6 +136,11 @@ def _check_full_batch(pkg, oracle, synth, torch, s, seed, plan=None, images=None
     x = torch.rand((s.N, s.C, s.H, s.W), device=dev, generator=gen) * 2 - 1
     top = plan.forward(x, torch.from_numpy(b).to(dev) if b is not None else None)
     torch.cuda.synchronize()
+    if full_ref is not None:
+        assert full_ref.shape == top.shape
+        scale = max(1e-6, float(full_ref.abs().max()))
+        full_err = float((top - full_ref).abs().max()) / scale
+        assert full_err <= TOL, "%s via %s: all %d images vs the generic kernel: %g" % (s.name, plan.kernel_name, s.N, full_err)
     imgs = sorted(set(i for i in (images or (0, 1, 3, s.N // 2, s.N - 2, s.N - 1)) if 0 <= i < s.N))
     idx = torch.tensor(imgs, device=dev)
     xs, got = x[idx].cpu().numpy(), top[idx].cpu().numpy()
@@ -134,12 +162,15 @@ def test_config_layers_at_config_batch_vs_oracle(pkg, oracle, synth, torch_cuda,
     the kernel path the headline numbers are measured on."""
     shapes = dict(_config_sets(synth))[which]
     for k, s in enumerate(shapes):
-        # AUTO: the walk is code WeightAlign generated (jit_codegen.h) ...
-        err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k, kernel=pkg.KERNEL_JIT)
+        # all N images of both fast kernels are compared on the device with the generic kernel (bit-exact
+        # to the oracle), six of them with the oracle itself
+        ref = _generic_reference(pkg, torch_cuda, s, 7000 + 10 * k)
+        # the walk as code WeightAlign generated (jit_codegen.h) ...
+        err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k, kernel=pkg.KERNEL_JIT, full_ref=ref)
         assert "escoin_sconv_jit_kernel" in name, (s.name, name)
         assert err <= TOL, "%s @N=%d via %s: %g" % (s.name, s.N, name, err)
         # ... and the LDS-staged stream kernel on the same layer
-        err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k, kernel=pkg.KERNEL_TILED)
+        err, name = _check_full_batch(pkg, oracle, synth, torch_cuda, s, 7000 + 10 * k, kernel=pkg.KERNEL_TILED, full_ref=ref)
         assert "tiled" in name, (s.name, name)
         assert err <= TOL, "%s @N=%d via %s: %g" % (s.name, s.N, name, err)
         # the 3x3 layers whose planes are whole 1 KiB pieces take the instantiation that issues the

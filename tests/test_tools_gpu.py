@@ -142,3 +142,66 @@ def test_forward_is_capturable_in_a_hip_graph(pkg, oracle, synth):
             assert rel_err(tops[k].cpu().numpy(), want) <= 1e-4, (s.name, rep)
     for p in plans:
         p.close()
+
+
+def test_export_import_aligned_round_trip(pkg, oracle, synth):
+    """escoin_plan_export_aligned -> escoin_plan_import_aligned: a generated-code plan restored from the
+    persisted blob (CSR + channel deal + unit table + code object) loads the code object as it is, computes
+    bit-identical outputs, and costs a fraction of WeightAlign; a blob for another batch / geometry falls back to
+    aligning from its CSR; a damaged blob is refused."""
+    import torch
+    dev = torch.device("cuda:0")
+    for s in (synth.resnet50_3x3(N=8)[2], synth.googlenet_1x1(N=8)[13], synth.alexnet(N=4)[0]):
+        w, b = synth.pruned_weights(s, 5), synth.bias_vector(s, 6)
+        x = torch.from_numpy(synth.activations(s, 7)).to(dev)
+        bd = torch.from_numpy(b).to(dev) if b is not None else None
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256)
+        plan.weight_align(w)
+        want = plan.forward(x, bd).cpu().numpy()
+        blob = plan.export_aligned()
+        assert plan.stat("code_bytes") > 0 and blob.size > plan.stat("code_bytes")
+        t_align = plan.align_ms
+        # (1) same options: the persisted code object is loaded as it is
+        p2 = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256)
+        assert p2.import_aligned(blob) is True
+        assert p2.kernel_name == plan.kernel_name and p2.tiling_info == plan.tiling_info
+        assert np.array_equal(p2.forward(x, bd).cpu().numpy(), want), s.name
+        assert p2.stat("code_bytes") == plan.stat("code_bytes")
+        rp, ci, va, ng = plan.get_csr()
+        rp2, ci2, va2, ng2 = p2.get_csr()
+        assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2) and np.array_equal(va, va2) and np.array_equal(ng, ng2)
+        assert np.array_equal(p2.export_aligned(), blob)          # and it can be persisted again
+        print("%s: weight_align %.1f ms, import_aligned %.1f ms" % (s.name, t_align, p2.align_ms))
+        # (2) another tiling batch: the code does not fit -- aligned from the CSR instead, same numbers
+        p3 = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT)
+        assert p3.import_aligned(blob) is False
+        got = p3.forward(x, bd).cpu().numpy()
+        assert float(np.abs(got - want).max()) <= 1e-4 * max(1e-6, float(np.abs(want).max()))
+        # (3) other weights' geometry, a truncated blob, a flipped magic: refused
+        other = pkg.Plan(pkg.ConvDesc.from_shape(s._replace(M=s.M * 2)))
+        for bad, p in ((blob, other), (blob[:-5], pkg.Plan(pkg.ConvDesc.from_shape(s))),
+                       (np.concatenate([blob[:1] ^ 0xFF, blob[1:]]), pkg.Plan(pkg.ConvDesc.from_shape(s)))):
+            with pytest.raises(pkg.EscoinError):
+                p.import_aligned(bad)
+        for q in (plan, p2, p3, other):
+            q.close()
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, group=s.group)
+    ref = oracle.conv_forward(g, x.cpu().numpy(), w, b, gate=False)
+    assert float(np.abs(want - ref).max()) <= 1e-4 * float(np.abs(ref).max())
+
+
+def test_caffe_test_chain_from_persisted_aligned_form(tmp_path):
+    """resnet50_chain: --save-aligned, then a second run --load-aligned: every layer restored without the
+    channel deal / generator / assembler, oracle check green."""
+    path = str(tmp_path / "chain_aligned.npz")
+    text = _tool("--model", "resnet50_chain", "--batch", "4", "--iterations", "1", "--save-aligned", path)
+    assert "aligned form of 52 layers written" in text, text
+    text = _tool("--model", "resnet50_chain", "--batch", "4", "--iterations", "1", "--load-aligned", path, "--check")
+    assert "16 code objects loaded as persisted" in text, text
+    assert "oracle check: worst relative error" in text
+
+
+def test_caffe_test_chain_prune_1x1_what_if():
+    text = _tool("--model", "resnet50_chain", "--batch", "4", "--iterations", "1", "--prune-1x1", "90", "--check")
+    assert "1x1 pruned @90 %" in text and "with the 1x1 layers on the sparse path" in text, text
+    assert text.count("oracle check: worst relative error") == 2

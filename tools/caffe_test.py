@@ -57,10 +57,12 @@ def model_layers(synth, model, batch, sparsity):
 _RESNET50_STAGES = [(64, 256, 3, 1), (128, 512, 4, 2), (256, 1024, 6, 2), (512, 2048, 3, 2)]
 
 
-def resnet50_chain(synth, batch, sparsity):
+def resnet50_chain(synth, batch, sparsity, sparsity_1x1=0.0):
     """[(name, kind, shape, relu, role)]: role in {"2a", "2b", "2c", "1"}; kind "sparse" for the
-    pruned 3x3 (branch2b), "dense" for the 1x1 ones (sparsity 0)."""
+    pruned 3x3 (branch2b), "dense" for the 1x1 ones (sparsity 0; with --prune-1x1 they are pruned too and
+    KERNEL_AUTO decides per layer what runs them)."""
     out = []
+    s1 = float(sparsity_1x1)
     cin, hw = 64, 56
     for si, (mid, cout, blocks, stride) in enumerate(_RESNET50_STAGES):
         for b in range(blocks):
@@ -69,48 +71,94 @@ def resnet50_chain(synth, batch, sparsity):
             ohw = hw // st
             if b == 0:
                 out.append((tag + "_branch1", "dense",
-                            synth.shape(tag + "_branch1", batch, cin, hw, hw, cout, 1, stride=st, bias=False, sparsity=0.0),
+                            synth.shape(tag + "_branch1", batch, cin, hw, hw, cout, 1, stride=st, bias=False, sparsity=s1),
                             False, "1"))
             out.append((tag + "_branch2a", "dense",
-                        synth.shape(tag + "_branch2a", batch, cin, hw, hw, mid, 1, stride=st, bias=False, sparsity=0.0),
+                        synth.shape(tag + "_branch2a", batch, cin, hw, hw, mid, 1, stride=st, bias=False, sparsity=s1),
                         True, "2a"))
             out.append((tag + "_branch2b", "sparse",
                         synth.shape(tag + "_branch2b", batch, mid, ohw, ohw, mid, 3, pad=1, bias=False, sparsity=sparsity),
                         True, "2b"))
             out.append((tag + "_branch2c", "dense",
-                        synth.shape(tag + "_branch2c", batch, mid, ohw, ohw, cout, 1, bias=False, sparsity=0.0),
+                        synth.shape(tag + "_branch2c", batch, mid, ohw, ohw, cout, 1, bias=False, sparsity=s1),
                         False, "2c"))
             cin, hw = cout, ohw
     return out
+
+
+def _npz_blobs(path):
+    z = np.load(path, allow_pickle=False)
+    return {k: z[k] for k in z.files}
 
 
 def run_chain(args, pkg, synth):
     import torch
     if not torch.cuda.is_available() or pkg.device_count() < 1:
         raise SystemExit("caffe_test.py needs a HIP device: the product path has no CPU fallback")
+    print("[cxh] GPU device name: %s" % torch.cuda.get_device_name(0))
+    base = _time_chain(args, pkg, synth, 0.0, "1x1 dense (the reference's EscConvolution layers)")
+    if args.prune_1x1 is None:
+        return 0
+    # the what-if BASELINE configs[4] implies: the chain's 1x1 weights pruned too, KERNEL_AUTO per layer
+    sp = args.prune_1x1 / 100.0
+    pruned = _time_chain(args, pkg, synth, sp, "1x1 pruned @%g %%, KERNEL_AUTO per layer" % args.prune_1x1)
+    print("[cxh] ResNet-50 chain, batch %d, conv time per forward pass (ms):" % (args.batch or 256))
+    print("%-46s %12s %12s %12s" % ("", "sparse 3x3", "1x1 layers", "CONV total"))
+    for label, r in (("1x1 dense (fp32 MFMA)", base), ("1x1 pruned @%g %% (KERNEL_AUTO)" % args.prune_1x1, pruned)):
+        print("%-46s %12.3f %12.3f %12.3f" % (label, r["sparse"], r["dense"], r["sparse"] + r["dense"]))
+    print("[cxh] Total CONV time: %.2f ms -> %.2f ms with the 1x1 layers on the sparse path (x%.2f)" %
+          (base["sparse"] + base["dense"], pruned["sparse"] + pruned["dense"],
+           (base["sparse"] + base["dense"]) / max(1e-9, pruned["sparse"] + pruned["dense"])))
+    kinds = {}
+    for name, kn in pruned["kernels"]:
+        kinds[kn] = kinds.get(kn, 0) + 1
+    print("kernels of the pruned chain: " + ", ".join("%d x %s" % (v, k) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])))
+    return 0
+
+
+def _time_chain(args, pkg, synth, sparsity_1x1, label):
+    import torch
     dev = torch.device("cuda", 0)
     batch = args.batch or 256
-    chain = resnet50_chain(synth, batch, 0.9 if args.sparsity is None else args.sparsity)
-    print("[cxh] GPU device name: %s" % torch.cuda.get_device_name(0))
+    chain = resnet50_chain(synth, batch, 0.9 if args.sparsity is None else args.sparsity, sparsity_1x1)
+    print("[cxh] --- %s ---" % label)
     plans, weights = [], []
+    persisted = _npz_blobs(args.load_aligned) if (args.load_aligned and sparsity_1x1 == 0.0) else None
+    need_w = persisted is None or args.check
     t0 = time.perf_counter()
-    align_ms = []
+    align_ms, t_gen, n_fast = [], 0.0, 0
     for i, (name, kind, s, relu, role) in enumerate(chain):
-        w = synth.pruned_weights(s, 1000 + 31 * i)
-        # keep the activations O(1) through 16 blocks: He-style scale for the surviving weights
-        w = (w * np.float32(np.sqrt(6.0 / max(1.0, (1.0 - s.sparsity) * w[0].size)))).astype(np.float32)
+        tg = time.perf_counter()
+        w = None
+        if need_w:
+            w = synth.pruned_weights(s, 1000 + 31 * i)
+            # keep the activations O(1) through 16 blocks: He-style scale for the surviving weights
+            w = (w * np.float32(np.sqrt(6.0 / max(1.0, (1.0 - s.sparsity) * w[0].size)))).astype(np.float32)
+        t_gen += time.perf_counter() - tg
         plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), conv_mode=args.conv_mode)
         if args.dense_gate:
             plan.set_option("dense_gate", 1)
         ta = time.perf_counter()
-        plan.weight_align(w)
+        if persisted is not None:
+            n_fast += int(plan.import_aligned(persisted[name]))      # the layer as a previous run left it
+        else:
+            plan.weight_align(w)
         align_ms.append(1e3 * (time.perf_counter() - ta))
         plans.append(plan)
         weights.append(w)
     torch.cuda.synchronize()
-    print("[cxh] WeightAlign of %d layers: %.1f ms (one-time, per weight load: net.cpp:819; slowest: %s)" %
-          (len(chain), 1e3 * (time.perf_counter() - t0),
+    total_ms = 1e3 * (time.perf_counter() - t0 - t_gen)
+    how = ("from %s: %d code objects loaded as persisted" % (args.load_aligned, n_fast)) if persisted is not None else \
+          "one-time, per weight load: net.cpp:819"
+    print("[cxh] WeightAlign of %d layers: %.1f ms (%s; slowest: %s)" %
+          (len(chain), total_ms, how,
            ", ".join("%s %.0f ms" % (chain[i][0], align_ms[i]) for i in sorted(range(len(chain)), key=lambda i: -align_ms[i])[:3])))
+    if args.save_aligned and sparsity_1x1 == 0.0:
+        ts = time.perf_counter()
+        np.savez(args.save_aligned, **{chain[i][0]: plans[i].export_aligned() for i in range(len(chain))})
+        print("[cxh] aligned form of %d layers written to %s (%.1f MB, %.0f ms)" %
+              (len(chain), args.save_aligned, os.path.getsize(args.save_aligned if args.save_aligned.endswith(".npz") else args.save_aligned + ".npz") / 1e6,
+               1e3 * (time.perf_counter() - ts)))
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     x0 = torch.rand((batch, 64, 56, 56), device=dev, generator=g) * 2 - 1
@@ -123,7 +171,7 @@ def run_chain(args, pkg, synth):
         a.record()
         y = plans[i].forward(x)
         b.record()
-        bucket.append((chain[i][1], a, b))
+        bucket.append((chain[i][1], a, b, i))
         if oracle is not None:
             s = chain[i][2]
             geom = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
@@ -141,11 +189,12 @@ def run_chain(args, pkg, synth):
         a.record()
         y = fn()
         b.record()
-        bucket.append(("other", a, b))
+        bucket.append(("other", a, b, -1))
         return y
 
     print("Running for %d iterations." % args.iterations)
     sums = {"sparse": 0.0, "dense": 0.0, "other": 0.0}
+    per_layer = np.zeros(len(chain))
     for it in range(args.iterations + 1):          # iteration 0 is an untimed warm-up
         bucket = []
         x = x0
@@ -168,8 +217,10 @@ def run_chain(args, pkg, synth):
         if it == 0:
             continue
         t = {"sparse": 0.0, "dense": 0.0, "other": 0.0}
-        for kind, a, b in bucket:
+        for kind, a, b, li in bucket:
             t[kind] += a.elapsed_time(b)
+            if li >= 0:
+                per_layer[li] += a.elapsed_time(b)
         for k in t:
             sums[k] += t[k]
         print("[cxh] Total CONV time: %.2f ms" % (t["sparse"] + t["dense"]))
@@ -177,11 +228,24 @@ def run_chain(args, pkg, synth):
     n = max(1, args.iterations)
     conv_t = (sums["sparse"] + sums["dense"]) / n
     print("[cxh] Average over %d iterations (batch %d): CONV %.3f ms (sparse 3x3 %.3f ms in 16 layers, "
-          "dense 1x1 %.3f ms in %d layers), other %.3f ms, total %.3f ms; conv / total = %.1f %%" %
-          (n, batch, conv_t, sums["sparse"] / n, sums["dense"] / n, len(chain) - 16, sums["other"] / n,
+          "%s 1x1 %.3f ms in %d layers), other %.3f ms, total %.3f ms; conv / total = %.1f %%" %
+          (n, batch, conv_t, sums["sparse"] / n, "pruned" if sparsity_1x1 > 0 else "dense", sums["dense"] / n,
+           len(chain) - 16, sums["other"] / n,
            (conv_t + sums["other"] / n), 100.0 * conv_t / max(1e-9, conv_t + sums["other"] / n)))
     print("kernels: sparse -> %s, dense -> %s" % (plans[2].kernel_name, plans[0].kernel_name))
-    return 0
+    if args.per_layer:
+        print("%-22s %-44s %9s %9s %8s" % ("layer", "kernel", "us", "TFLOP/s", "GB/s"))
+        for li, (name, kind, s, relu, role) in enumerate(chain):
+            us = 1e3 * per_layer[li] / n
+            dense_fl = 2.0 * batch * s.M * (s.C // s.group) * s.KH * s.KW * synth.out_hw(s)[0] * synth.out_hw(s)[1]
+            fl = dense_fl if "dense_mfma" in plans[li].kernel_name else synth.flops(s)
+            print("%-22s %-44s %9.1f %9.2f %8.0f" % (name, plans[li].kernel_name[:44], us, fl / us * 1e-6,
+                                                    synth.algorithmic_bytes(s) / us * 1e-3))
+    out = {"sparse": sums["sparse"] / n, "dense": sums["dense"] / n, "other": sums["other"] / n,
+           "kernels": [(chain[i][0], plans[i].kernel_name) for i in range(len(chain))], "align_ms": total_ms}
+    for p in plans:
+        p.close()
+    return out
 
 
 def main():
@@ -198,6 +262,15 @@ def main():
     ap.add_argument("--dense-gate", action="store_true",
                     help="honour the reference's density > 0.2 -> dense GEMM gate")
     ap.add_argument("--check", action="store_true", help="compare with the CPU oracle (first 2 images)")
+    ap.add_argument("--prune-1x1", type=float, default=None, metavar="PCT",
+                    help="resnet50_chain: a second pass with the 1x1 weights pruned at PCT %% and KERNEL_AUTO per "
+                         "layer; both `[cxh] Total CONV time` buckets side by side")
+    ap.add_argument("--save-aligned", default=None, metavar="FILE.npz",
+                    help="resnet50_chain: persist every layer's aligned form (escoin_plan_export_aligned: CSR, "
+                         "channel deal, unit table, code object)")
+    ap.add_argument("--load-aligned", default=None, metavar="FILE.npz",
+                    help="resnet50_chain: restore the layers from --save-aligned's file instead of WeightAlign")
+    ap.add_argument("--per-layer", action="store_true", help="resnet50_chain: per-layer table")
     ap.add_argument("--tilings", action="store_true", help="print how every layer's plan tiles it (escoin_plan_tiling_info)")
     args = ap.parse_args()
 
