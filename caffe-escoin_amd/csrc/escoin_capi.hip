@@ -153,9 +153,11 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
       //   sparse = 25 us + 2 * pixels * nonzeros at 68 TFLOP/s (3x3 / 5x5) or 58 (1x1), no faster than the
       //            blobs at 4.8 TB/s.
       // Worst regret over the 14 shapes x 12 sparsities of the table: 6.6 % (a fixed 50 % cut: 42 %).  The model
-      // only ever decides ABOVE the cut; below it the sparse kernel always won.  An explicit
-      // dense_threshold_pct option is obeyed as given.
+      // only ever decides ABOVE the cut; below it the sparse kernel always won, and above 90 % density the dense one
+      // (an unpruned layer is never turned into megabytes of code).  An explicit dense_threshold_pct option is
+      // obeyed as given.
       auto model_says_dense = [&](long nnz_g) {
+        if ((double)nnz_g > 0.9 * per_group) return true;
         const double n = (double)(p->tiling_batch > 0 ? p->tiling_batch : g.d.N);
         const double pix = n * g.OH * g.OW;
         const int tm = g.Mg <= 64 ? 64 : 128;

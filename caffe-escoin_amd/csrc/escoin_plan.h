@@ -59,6 +59,7 @@ struct TiledConfig {
   bool jit_dma = false;      // ... and its units stage the next block's planes themselves (jit_codegen.h DmaPlan)
   int dma_period = 0;        // quads covered by the quad table (lcm of the plane size and 64)
   int jit_pref = 0;          // code touches at the start of every unit
+  bool jit_chain = false;    // a tile's units run as one chain (jit_codegen.h ChainPlan)
   std::string info;          // escoin_plan_tiling_info
 };
 

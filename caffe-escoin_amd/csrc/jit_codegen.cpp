@@ -75,8 +75,9 @@ struct Lds {
 
 // n_pref > 0: the unit starts with n_pref loads over the next unit's code; returns the index (in
 // `c`) of the distance literal to patch (0: none).
+// blk / n_icb: which block of its oc-group's chain this unit is (chaining only).
 size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const std::vector<Piece> &pieces,
-                 const Options &opt_in, int n_pref, int wave) {
+                 const Options &opt_in, int n_pref, int wave, int blk, int n_icb) {
   Options opt = opt_in;
   if (opt.prio_waves > 0 && (wave < 0 || wave >= opt.prio_waves)) opt.prio_rows = 0;
   size_t patch = 0;
@@ -92,6 +93,11 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
         enc_s_addc(c, kSPref + 1, false);
       }
     }
+  }
+  if (opt.chain.on && blk > 0 && blk == n_icb - opt.dma.ahead) {
+    // from this unit on the pieces belong to the NEXT tile: its quad table, its record count
+    enc_s_mov(c, kSRecords, kSNextRecords);
+    enc_v_add_u32_s(c, kVTabAddr, kSTabDelta, kVTabAddr);
   }
   const int n = (opt.ablate & 8) ? 0 : (int)rows.size();
   // Without a tile B the 24 input registers hold SIX quads instead of three pairs: rows are read five
@@ -198,6 +204,26 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     issue_pieces(-1);
   }
   if (opt.prio_rows > 0 && prio) enc_setprio(c, 0);
+  if (opt.chain.on && blk + 1 < n_icb) {
+    // on to the next block without leaving the code.  Everything this wave issued for the block about to be
+    // walked must have landed: with one fill in flight that is all of it; with two, all but this unit's own
+    // vector-memory operations (its code touches and its pieces, which stage the block after the next).
+    const int younger = opt.dma.ahead >= 2 ? n_pref + (int)pieces.size() : 0;
+    enc_waitcnt_vm(c, std::min(63, younger));
+    enc_barrier(c);
+    const uint32_t all = (uint32_t)opt.chain.nbuf * opt.chain.buf_bytes;
+    enc_s_mov(c, kSChainTmp, kSWalkBase);
+    enc_s_add_u32_lit(c, kSWalkBase, kSWalkBase, opt.chain.buf_bytes);
+    enc_s_cmp_lt_u32_lit(c, kSWalkBase, all);
+    enc_s_cselect_or_zero(c, kSWalkBase, kSWalkBase);
+    enc_s_sub_u32(c, kSChainTmp, kSWalkBase, kSChainTmp);          // (mod 2^32: also when the buffer wraps)
+    enc_v_add_u32_s(c, kVAddrA, kSChainTmp, kVAddrA);
+    if (!opt.one_tile) enc_v_add_u32_s(c, kVAddrB, kSChainTmp, kVAddrB);
+    enc_s_add_u32_lit(c, kSFillBase, kSFillBase, opt.chain.buf_bytes);
+    enc_s_cmp_lt_u32_lit(c, kSFillBase, all);
+    enc_s_cselect_or_zero(c, kSFillBase, kSFillBase);
+    return patch;       // (the next unit follows: alignment padding is s_nop)
+  }
   enc_setpc_return(c);
   return patch;
 }
@@ -272,7 +298,7 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
         while ((p.code.size() * 4) % kUnitAlign) enc_nop(p.code);
         p.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk] = (uint32_t)(p.code.size() * 4);
         const size_t at = p.code.size();
-        patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref, t.pix_waves == 1 ? ocg % t.oc_waves : -1));
+        patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref, t.pix_waves == 1 ? ocg % t.oc_waves : -1, blk, t.n_icb));
         *max_unit_bytes = std::max(*max_unit_bytes, (p.code.size() - at) * 4);
       }
   // the distances: unit (cg, ocg, blk) touches the code of (cg, ocg, (blk + 1) % n_icb)
@@ -287,6 +313,7 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
   // instruction prefetch and the code touches run past the last unit: keep them inside the blob
   for (int i = 0; i < 64 + n_pref * 1024; ++i) enc_nop(p.code);
   p.n_pref = n_pref;
+  p.chained = opt.chain.on;
   return p;
 }
 
@@ -294,6 +321,7 @@ Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std:
                       const std::vector<std::vector<int>> &colidx,
                       const std::vector<std::vector<float>> &values, const Options &opt_in) {
   Options opt = opt_in;
+  if (!opt.dma.on || t.n_ocg % std::max(1, t.oc_waves) != 0 || t.pix_waves != 1) opt.chain.on = false;
   // Tile B (the lane's second quad: flattened rows rows_per_slab .. 2 rows_per_slab - 1) lies past the
   // workgroup's last row when all of them fit tile A -- every small pointwise image walked one (or a
   // few) to a workgroup: no reads, no FMAs for it (the kernel's epilogue stores none of its lanes)

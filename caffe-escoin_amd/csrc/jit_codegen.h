@@ -113,6 +113,36 @@ inline void enc_global_load_dword(std::vector<uint32_t> &c, int vdst, int vaddr,
   c.push_back((uint32_t)vaddr | ((uint32_t)saddr << 16) | ((uint32_t)vdst << 24));
 }
 inline void enc_setpc_return(std::vector<uint32_t> &c) { c.push_back(0xBE801D1Eu); }   // s_setpc_b64 s[30:31]
+// ---- block-to-block chaining (ChainPlan below) ----
+// s_waitcnt vmcnt(n)   (expcnt, lgkmcnt not waited for; n <= 63)
+inline void enc_waitcnt_vm(std::vector<uint32_t> &c, int n) {
+  c.push_back(0xBF8C0F70u | (uint32_t)(n & 15) | ((uint32_t)((n >> 4) & 3) << 14));
+}
+inline void enc_barrier(std::vector<uint32_t> &c) { c.push_back(0xBF8A0000u); }          // s_barrier
+// s_mov_b32 s<sdst>, s<ssrc>
+inline void enc_s_mov(std::vector<uint32_t> &c, int sdst, int ssrc) { c.push_back(0xBE800000u | ((uint32_t)sdst << 16) | (uint32_t)ssrc); }
+// s_add_u32 s<sdst>, s<s0>, <literal>
+inline void enc_s_add_u32_lit(std::vector<uint32_t> &c, int sdst, int s0, uint32_t lit) {
+  c.push_back(0x8000FF00u | ((uint32_t)sdst << 16) | (uint32_t)s0);
+  c.push_back(lit);
+}
+// s_sub_u32 s<sdst>, s<s0>, s<s1>
+inline void enc_s_sub_u32(std::vector<uint32_t> &c, int sdst, int s0, int s1) {
+  c.push_back(0x80800000u | ((uint32_t)sdst << 16) | ((uint32_t)s1 << 8) | (uint32_t)s0);
+}
+// s_cmp_lt_u32 s<s0>, <literal>
+inline void enc_s_cmp_lt_u32_lit(std::vector<uint32_t> &c, int s0, uint32_t lit) {
+  c.push_back(0xBF0AFF00u | (uint32_t)s0);
+  c.push_back(lit);
+}
+// s_cselect_b32 s<sdst>, s<s0>, 0
+inline void enc_s_cselect_or_zero(std::vector<uint32_t> &c, int sdst, int s0) {
+  c.push_back(0x85008000u | ((uint32_t)sdst << 16) | (uint32_t)s0);
+}
+// v_add_u32 v<vdst>, s<ssrc>, v<vsrc>
+inline void enc_v_add_u32_s(std::vector<uint32_t> &c, int vdst, int ssrc, int vsrc) {
+  c.push_back(0x68000000u | ((uint32_t)vdst << 17) | ((uint32_t)vsrc << 9) | (uint32_t)ssrc);
+}
 inline void enc_setprio(std::vector<uint32_t> &c, int p) { c.push_back(0xBF8F0000u | (uint32_t)(p & 3)); }
 inline void enc_nop(std::vector<uint32_t> &c) { c.push_back(0xBF800000u); }
 
@@ -128,6 +158,26 @@ struct DmaPlan {
   int ahead = 1;            // the unit of block k stages block k + ahead (plane buffers - 1: 1, or 2 when two
                             // fills are kept in flight)
 };
+
+// Block-to-block chaining: the units of one (conv group, oc-group) lie back to back in block order, and
+// with this on a unit does not return to the kernel body after its block -- it waits for its own pieces of
+// the next block (a counted s_waitcnt vmcnt: the count is static), joins the workgroup barrier, moves its
+// LDS addresses on to the next plane buffer and FALLS THROUGH into the next block's unit; only the last
+// block's unit returns.  The body enters a tile's chain once and comes back for the epilogue.  What the
+// compiled block top cost (unit offset from LDS, fill bookkeeping, two integer divisions, SGPR spills:
+// ~1300 cycles per block, 9-12 % of a ResNet launch, profiles/r04_stamp_profile.md) becomes ~14
+// instructions around the barrier.  Needs: the code's own plane DMA (DmaPlan), every wave of every
+// workgroup with an oc-group (the barriers are counted in code).  Extra registers:
+//   s52  byte offset of the plane buffer being WALKED (s48: the one being filled); v32 / v33 follow it
+//   s53  num_records for fills that belong to the NEXT tile (0 when there is none), moved into s46 by the
+//        first unit that stages the next tile; s54 = byte distance from this tile's quad table to the next
+//        tile's (added to v34 at the same point); s55 scratch
+struct ChainPlan {
+  bool on = false;
+  int nbuf = 2;             // plane buffers
+  uint32_t buf_bytes = 0;   // bytes of one plane buffer
+};
+constexpr int kSWalkBase = 52, kSNextRecords = 53, kSTabDelta = 54, kSChainTmp = 55, kSRecords = 46;
 
 // Smallest period lcm(qpc', 64) <= max_period over qpc' in [qpc, qpc * (1 + slack)]: *padded = qpc'
 // (0: none).  A plane may be padded by a few quads so that the table stays small.
@@ -154,6 +204,7 @@ struct Options {
   int ablate = 0;         // timing experiments only (ESCOIN_JIT_ABL; wrong results): 1 no FMAs, 2 no LDS
                           // reads, 4 no weight moves, 8 empty units
   DmaPlan dma;
+  ChainPlan chain;
   int prefetch = 1;       // touch the next unit's code (above)
   int one_tile = 0;       // set by build_program: the tiling leaves tile B without rows, its reads and FMAs
                           // are not generated (-1: never, ESCOIN_JIT_ONE_TILE=0)
@@ -167,6 +218,7 @@ struct Program {
   long n_rows = 0, n_records = 0, n_dma = 0;
   int n_pref = 0;                   // code touches (plain loads) at the start of every unit
   bool overflow = false;            // an LDS offset does not fit the instruction's 16-bit field
+  bool chained = false;             // the units of an oc-group run as one chain per tile (ChainPlan)
 };
 
 Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,

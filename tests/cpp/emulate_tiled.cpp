@@ -35,25 +35,53 @@ struct JitWave {
   JitWave() : v(64 * 256, 0.f) {}
 };
 struct PendingRead { int vdst; int n; std::vector<float> data; };   // data: [64][n]
-struct DmaPiece { uint32_t m0, soff; unsigned long long exec; std::vector<uint32_t> voff; bool nt; };
+struct DmaPiece { uint32_t m0, soff; unsigned long long exec; std::vector<uint32_t> voff; bool nt; uint32_t records = 0; bool next_table = false; int vm_id = -1; };
 struct JitPref { long long base = -1; int touches = 0; };
 static size_t last_return_pc = 0;   // code touches of a unit: first address, count
 struct JitDmaCtx {
   const std::vector<uint32_t> *tabx = nullptr;   // the quad table of the tile being staged (period entries)
   uint32_t fill_base = 0;
   std::vector<DmaPiece> issued;
+  // chained units (jit_codegen.h ChainPlan): the NEXT tile's table (reached once v34 has moved by tab_delta)
+  const std::vector<uint32_t> *tabx_next = nullptr;
+};
+// What a chain of units (one tile of one wave) runs against: one LDS image per block, the buffer rotation,
+// and a hook at every in-code barrier that checks the pieces the unit just finished has issued.
+struct JitChainCtx {
+  const std::vector<std::vector<float>> *lds_of_block = nullptr;
+  int nbuf = 2, n_icb = 1, ahead = 1;
+  uint32_t buf_bytes = 0, walk_base0 = 0, fill_base0 = 0, records_cur = 0x1000, records_next = 0x2000, tab_delta = 0x40;
+  int blk = 0;                 // block being walked
+  int barriers = 0;
+  std::vector<size_t> unit_first_piece;    // index into JitDmaCtx::issued of each unit's first piece
+  std::vector<JitPref> prefs;              // code touches per unit
+  std::vector<size_t> unit_end;            // pc just past each unit's last instruction
 };
 
 static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w, const std::vector<float> &lds,
                         const std::vector<uint32_t> &laneA /* LDS byte address of the lane's tile-A quad */,
-                        JitDmaCtx *dma = nullptr, JitPref *pref = nullptr) {
+                        JitDmaCtx *dma = nullptr, JitPref *pref = nullptr, JitChainCtx *chain = nullptr) {
   long long s50 = -1;
+  uint32_t addr_shift = 0, addr_shift_b = 0, tab_shift = 0;   // what the code has added to v32 / v33 / v34
+  bool scc = false;
+  std::vector<int> vm_out;     // outstanding vector-memory operations of this wave, oldest first: block a piece stages, -1 = code touch
+  int vm_next_id = 0;
+  (void)vm_next_id;
   std::vector<PendingRead> pending;
   uint32_t sreg[128] = {0};
   uint32_t m0 = 0;
   unsigned long long exec = ~0ull;
   bool tab_unissued[256] = {false};     // a table entry was read into this register and its piece has not gone out
   if (dma) sreg[48] = dma->fill_base;
+  if (chain) {
+    sreg[52] = chain->walk_base0; sreg[48] = chain->fill_base0; sreg[53] = chain->records_next; sreg[54] = chain->tab_delta;
+    sreg[46] = chain->n_icb <= chain->ahead ? chain->records_next : chain->records_cur;
+    addr_shift = addr_shift_b = chain->walk_base0;
+    tab_shift = chain->n_icb <= chain->ahead ? chain->tab_delta : 0u;
+    chain->unit_first_piece.assign(1, 0);
+    chain->prefs.assign(1, JitPref());
+    pref = &chain->prefs.back();
+  }
   auto retire_to = [&](size_t keep) {
     while (pending.size() > keep) {
       const PendingRead &r = pending.front();
@@ -74,6 +102,10 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       if (!pending.empty()) { printf("jit: unit returns with LDS reads pending\n"); return 3; }
       if (exec != ~0ull) { printf("jit: unit returns with a partial EXEC\n"); return 3; }
       last_return_pc = pc;
+      if (chain) {
+        if (chain->blk != chain->n_icb - 1) { printf("jit chain: returned after block %d of %d\n", chain->blk, chain->n_icb); return 3; }
+        chain->unit_end.push_back(pc + 4);
+      }
       return 0;
     }
     if (d0 == 0xBEFE01C1u) { exec = ~0ull; pc += 4; continue; }   // s_mov_b64 exec, -1
@@ -91,10 +123,69 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       if (pref->touches == 0) pref->base = s50;
       else if (s50 != pref->base + 4096ll * pref->touches) { printf("jit: code touches not contiguous\n"); return 3; }
       pref->touches++;
+      vm_out.push_back(-1);
       pc += 8;
       continue;
     }
-    if ((d0 & 0xFFFF0000u) == 0xBF8C0000u) {   // s_waitcnt
+    if ((d0 & 0xFFFF0000u) == 0xBF8C0000u && (d0 & 0x0F70u) == 0x0F70u && (d0 & 0xF0FFu) != 0xC07Fu) {   // s_waitcnt vmcnt(n)
+      if (!chain) { printf("jit: s_waitcnt vmcnt outside a chain\n"); return 3; }
+      const size_t n = (d0 & 15u) | (((d0 >> 14) & 3u) << 4);
+      while (vm_out.size() > n) vm_out.erase(vm_out.begin());     // (in order: LDS-DMA and plain loads retire oldest first)
+      pc += 4;
+      continue;
+    }
+    if (d0 == 0xBF8A0000u) {   // s_barrier: the chain moves on to the next block
+      if (!chain) { printf("jit: s_barrier outside a chain\n"); return 3; }
+      if (!pending.empty()) { printf("jit chain: barrier with LDS reads pending\n"); return 3; }
+      if (exec != ~0ull) { printf("jit chain: barrier with a partial EXEC\n"); return 3; }
+      for (int b : vm_out)      // (entries: the step a piece stages, counted on from this tile's block 0)
+        if (b == chain->blk + 1) { printf("jit chain: block %d entered with its own pieces in flight\n", chain->blk + 1); return 3; }
+      chain->barriers++;
+      chain->unit_end.push_back(pc + 4);
+      chain->blk++;
+      if (chain->blk >= chain->n_icb) { printf("jit chain: more barriers than blocks\n"); return 3; }
+      chain->unit_first_piece.push_back(dma ? dma->issued.size() : 0);
+      chain->prefs.push_back(JitPref());
+      pref = &chain->prefs.back();
+      s50 = -1;
+      pc += 4;
+      continue;
+    }
+    if ((d0 & 0xFF80FF00u) == 0xBE800000u && (d0 & 0xFFu) < 102u) {   // s_mov_b32 s, s
+      sreg[(d0 >> 16) & 0x7F] = sreg[d0 & 0xFF];
+      pc += 4;
+      continue;
+    }
+    if ((d0 & 0xFF80FF00u) == 0x8000FF00u && ((d0 >> 16) & 0x7F) != 50 && ((d0 >> 16) & 0x7F) < 102) {   // s_add_u32 s, s, literal (not the code-touch address)
+      sreg[(d0 >> 16) & 0x7F] = sreg[d0 & 0xFF] + code[pc / 4 + 1];
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFF800000u) == 0x80800000u) {   // s_sub_u32 s, s, s
+      sreg[(d0 >> 16) & 0x7F] = sreg[d0 & 0xFF] - sreg[(d0 >> 8) & 0xFF];
+      pc += 4;
+      continue;
+    }
+    if ((d0 & 0xFFFFFF00u) == 0xBF0AFF00u) {   // s_cmp_lt_u32 s, literal
+      scc = sreg[d0 & 0xFF] < code[pc / 4 + 1];
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFF80FF00u) == 0x85008000u) {   // s_cselect_b32 s, s, 0
+      sreg[(d0 >> 16) & 0x7F] = scc ? sreg[d0 & 0xFF] : 0u;
+      pc += 4;
+      continue;
+    }
+    if ((d0 & 0xFE000000u) == 0x68000000u && (d0 & 0x1FFu) < 102u) {   // v_add_u32 v, s, v: the chain's address registers only
+      const int vd = (int)((d0 >> 17) & 0xFF), vs = (int)((d0 >> 9) & 0xFF);
+      if (!chain || vd != vs || (vd != 32 && vd != 33 && vd != 34)) { printf("jit: unexpected v_add_u32 v%d, s, v%d\n", vd, vs); return 3; }
+      if (vd == 32) addr_shift += sreg[d0 & 0x1FF];
+      else if (vd == 33) addr_shift_b += sreg[d0 & 0x1FF];
+      else tab_shift += sreg[d0 & 0x1FF];
+      pc += 4;
+      continue;
+    }
+    if ((d0 & 0xFFFF0000u) == 0xBF8C0000u) {   // s_waitcnt lgkmcnt(n)
       if ((d0 & 0xF0FFu) != 0xC07Fu) { printf("jit: unexpected s_waitcnt fields\n"); return 3; }
       retire_to((d0 >> 8) & 15);
       pc += 4;
@@ -111,9 +202,20 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       r.vdst = vdst;
       r.n = 4;
       r.data.resize(64 * 4);
+      const std::vector<float> *img = &lds;
+      uint32_t shift = 0;
+      if (chain) {
+        // the address registers must point into the buffer the rotation has reached, and what is there is this block's image
+        const uint32_t sh = vaddr == 33 ? addr_shift_b : addr_shift;
+        const uint32_t want_buf = (chain->walk_base0 / chain->buf_bytes + (uint32_t)chain->blk) % (uint32_t)chain->nbuf;
+        if (sh != want_buf * chain->buf_bytes) { printf("jit chain: block %d reads buffer offset %u, rotation says %u\n", chain->blk, sh, want_buf * chain->buf_bytes); return 3; }
+        if (sh != sreg[52]) { printf("jit chain: v32 and s52 disagree\n"); return 3; }
+        img = &(*chain->lds_of_block)[chain->blk];
+        (void)shift;
+      }
       for (int lane = 0; lane < 64; ++lane) {
         const size_t a = ((size_t)laneA[lane] + (vaddr == 33 ? 1024u : 0u) + off) / 4;
-        for (int e = 0; e < 4; ++e) r.data[lane * 4 + e] = (a + e < lds.size()) ? lds[a + e] : 0.f;
+        for (int e = 0; e < 4; ++e) r.data[lane * 4 + e] = (a + e < img->size()) ? (*img)[a + e] : 0.f;
       }
       pending.push_back(r);
       if (pending.size() > 15) { printf("jit: more than 15 LDS reads in flight\n"); return 3; }
@@ -139,10 +241,15 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       r.vdst = vdst;
       r.n = 1;
       r.data.resize(64);
+      const std::vector<uint32_t> *tb = dma->tabx;
+      if (chain) {
+        if (tab_shift != 0 && tab_shift != chain->tab_delta) { printf("jit chain: table address moved by %u\n", tab_shift); return 3; }
+        if (tab_shift) tb = dma->tabx_next;
+      }
       for (int lane = 0; lane < 64; ++lane) {
         const size_t e = off / 4 + lane;
-        if (e >= dma->tabx->size()) { printf("jit: table read past the table\n"); return 3; }
-        uint32_t u = (*dma->tabx)[e];
+        if (e >= tb->size()) { printf("jit: table read past the table\n"); return 3; }
+        uint32_t u = (*tb)[e];
         std::memcpy(&r.data[lane], &u, 4);
       }
       pending.push_back(r);
@@ -164,6 +271,15 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       pcs.m0 = m0; pcs.soff = sreg[49]; pcs.exec = exec; pcs.nt = (d0 >> 17) & 1;
       pcs.voff.resize(64);
       for (int lane = 0; lane < 64; ++lane) std::memcpy(&pcs.voff[lane], &w.v[(size_t)lane * 256 + vaddr], 4);
+      pcs.records = sreg[46];
+      pcs.next_table = tab_shift != 0;
+      if (chain) {
+        if (sreg[48] != ((chain->fill_base0 / chain->buf_bytes + (uint32_t)chain->blk) % (uint32_t)chain->nbuf) * chain->buf_bytes) {
+          printf("jit chain: block %d fills buffer offset %u\n", chain->blk, sreg[48]);
+          return 3;
+        }
+        vm_out.push_back(chain->blk + chain->ahead);
+      }
       dma->issued.push_back(pcs);
       pc += 8;
       continue;
@@ -236,6 +352,10 @@ static int run(const Case &cs, bool use_jit) {
       jo.dma.nt = (cs.N & 2) != 0;
       jo.dma.spread_pct = 40 + 10 * (cs.M % 5);
       jo.dma.ahead = (t.n_icb >= 2 && (cs.C & 1)) ? 2 : 1;      // two fills in flight: the unit of block k stages block k + 2
+      // a tile's units as one chain (where every wave has an oc-group: build_program decides); off for some image sizes
+      jo.chain.on = jo.dma.on && (cs.H % 3 != 0);
+      jo.chain.nbuf = jo.dma.ahead + 1;
+      jo.chain.buf_bytes = (uint32_t)((t.planes_bytes + 1023) / 1024 * 1024 + 1024);
     }
     jdma = jo.dma;
     jp = jit::build_program(g, t, rp, ci, va, jo);
@@ -289,8 +409,7 @@ static int run(const Case &cs, bool use_jit) {
       for (int ocblk = 0; ocblk < t.n_ocblk; ++ocblk) {
         // per-wave accumulators: [wave][lane][192]
         std::vector<float> acc((size_t)t.waves * 64 * kAccAll, 0.f);
-        for (int blk = 0; blk < t.n_icb; ++blk) {
-          // ---- fill ----
+        auto fill_block = [&](int blk, std::vector<float> &lds) {
           std::fill(lds.begin(), lds.end(), 0.f);
           for (int icl = 0; icl < t.icb; ++icl) {
             const int ic = blk * t.icb + icl;
@@ -309,6 +428,108 @@ static int run(const Case &cs, bool use_jit) {
               }
             }
           }
+        };
+        // the synthetic quad tables of "this tile" and "the next tile" (chained units use both), period entries each
+        auto make_tables = [&](uint32_t base, std::vector<uint32_t> &tab, std::vector<uint32_t> &tabx) {
+          tab.assign(jdma.on ? jdma.qpc : 0, 0u);
+          tabx.assign(jdma.on ? jdma.period : 0, 0u);
+          for (size_t f = 0; f < tab.size(); ++f) tab[f] = (f % 7 == 3) ? 0xFFFFFFF0u : (uint32_t)(base + 16 * f);
+          for (size_t e = 0; e < tabx.size(); ++e) {
+            const size_t c = e / jdma.qpc, f = e % jdma.qpc;
+            tabx[e] = tab[f] == 0xFFFFFFF0u ? 0xFFFFFFF0u : tab[f] + (uint32_t)(c * jdma.chan_bytes);
+          }
+        };
+        // checks the pieces one unit issued: this wave's share of block `nb`'s image, every lane from the right
+        // table entry and channel
+        auto check_pieces = [&](const std::vector<DmaPiece> &issued, size_t first, size_t last, int ocg, int nb, uint32_t fill_base,
+                                const std::vector<uint32_t> &tab) -> int {
+          const int nch = std::min(t.icb, g.Cg - nb * t.icb);
+          const long total = (long)nch * jdma.qpc;
+          const int n_instr = (int)((total + 63) / 64);
+          std::vector<int> seen(n_instr, 0);
+          for (size_t pi = first; pi < last; ++pi) {
+            const DmaPiece &pcs = issued[pi];
+            const uint32_t rel = pcs.m0 - fill_base;
+            if (rel % 1024 || (int)(rel / 1024) >= n_instr) { printf("jit dma: bad LDS address m0=%u fill_base=%u n_instr=%d nb=%d\n", pcs.m0, fill_base, n_instr, nb); return 3; }
+            const int i = (int)(rel / 1024);
+            if (i % 8 != ocg % 8) { printf("jit dma: piece %d issued by wave %d\n", i, ocg % 8); return 3; }
+            seen[i]++;
+            if (pcs.nt != jdma.nt) { printf("jit dma: nt flag\n"); return 3; }
+            for (int lane = 0; lane < 64; ++lane) {
+              const long e = (long)i * 64 + lane;
+              const bool on = (pcs.exec >> lane) & 1ull;
+              if (on != (e < total)) { printf("jit dma: lane %d of piece %d: exec %d, in image %d\n", lane, i, (int)on, (int)(e < total)); return 3; }
+              if (!on) continue;
+              const long icl = e / jdma.qpc, f = e % jdma.qpc;
+              if (tab[f] == 0xFFFFFFF0u) {
+                if (pcs.voff[lane] != 0xFFFFFFF0u) { printf("jit dma: halo quad not marked\n"); return 3; }
+              } else {
+                const uint32_t want_g = tab[f] + (uint32_t)(((long)nb * t.icb + icl) * jdma.chan_bytes);
+                if (pcs.voff[lane] == 0xFFFFFFF0u || pcs.voff[lane] + pcs.soff != want_g) { printf("jit dma: piece %d lane %d reads %u, want %u\n", i, lane, pcs.voff[lane] + pcs.soff, want_g); return 3; }
+              }
+            }
+          }
+          for (int i = ocg % 8; i < n_instr; i += 8)
+            if (seen[i] != 1) { printf("jit dma: piece %d issued %d times\n", i, seen[i]); return 3; }
+          return 0;
+        };
+        if (use_jit && jp.chained) {
+          // ---- chained units: a wave runs the tile's blocks as ONE call ----
+          std::vector<std::vector<float>> lds_of_block(t.n_icb, std::vector<float>((size_t)t.icb * t.plane_ch_floats));
+          for (int blk = 0; blk < t.n_icb; ++blk) fill_block(blk, lds_of_block[blk]);
+          const uint32_t buf_bytes = (uint32_t)((t.planes_bytes + 1023) / 1024 * 1024 + 1024);
+          std::vector<uint32_t> tab_cur, tabx_cur, tab_nxt, tabx_nxt;
+          make_tables(4096u, tab_cur, tabx_cur);
+          make_tables(1u << 20, tab_nxt, tabx_nxt);
+          for (int wave = 0; wave < t.waves; ++wave) {
+            const int pw = wave % t.pix_waves, ow_ = wave / t.pix_waves;
+            const int ocg = ocblk * t.oc_waves + ow_;
+            if (ocg >= t.n_ocg) { printf("jit chain: a wave without an oc-group\n"); return 3; }
+            JitWave jw;
+            std::vector<uint32_t> laneA(64);
+            for (int lane = 0; lane < 64; ++lane) {
+              const int fr = (pw * t.tpl) * t.rows_per_slab + lane / t.S4;
+              laneA[lane] = (uint32_t)(((size_t)fr * t.RS + 4 * (lane % t.S4)) * 4);
+            }
+            JitChainCtx cc;
+            cc.lds_of_block = &lds_of_block;
+            cc.nbuf = jdma.ahead + 1; cc.n_icb = t.n_icb; cc.ahead = jdma.ahead; cc.buf_bytes = buf_bytes;
+            const int c_buf0 = (tile * 7 + cg) % cc.nbuf;            // wherever the rotation happens to stand at the tile's start
+            cc.walk_base0 = (uint32_t)c_buf0 * buf_bytes;
+            cc.fill_base0 = (uint32_t)((c_buf0 + cc.ahead) % cc.nbuf) * buf_bytes;
+            JitDmaCtx dctx;
+            dctx.tabx = &tabx_cur;
+            dctx.tabx_next = &tabx_nxt;
+            const size_t ui0 = ((size_t)cg * t.n_ocg + ocg) * t.n_icb;
+            const int rc = jit_run_unit(jp.code, jp.unit_off[ui0], jw, lds_of_block[0], laneA, &dctx, nullptr, &cc);
+            if (rc) return rc;
+            if (cc.barriers != t.n_icb - 1 || (int)cc.unit_end.size() != t.n_icb) { printf("jit chain: %d barriers for %d blocks\n", cc.barriers, t.n_icb); return 3; }
+            cc.unit_first_piece.push_back(dctx.issued.size());
+            for (int blk = 0; blk < t.n_icb; ++blk) {
+              const size_t ui = ui0 + blk;
+              // where each unit starts: the chain must have passed through every unit's own entry
+              if (blk > 0 && jp.unit_off[ui] < cc.unit_end[blk - 1]) { printf("jit chain: unit %d overlaps its predecessor\n", blk); return 3; }
+              pref_of[ui] = cc.prefs[blk];
+              unit_end[ui] = cc.unit_end[blk];
+              const bool next_tile = blk + cc.ahead >= t.n_icb;
+              const int nb = (blk + cc.ahead) % t.n_icb;
+              const uint32_t fill_base = (uint32_t)((c_buf0 + blk + cc.ahead) % cc.nbuf) * buf_bytes;
+              for (size_t pi = cc.unit_first_piece[blk]; pi < cc.unit_first_piece[blk + 1]; ++pi) {
+                if (dctx.issued[pi].next_table != next_tile) { printf("jit chain: unit %d staged through the wrong tile's table\n", blk); return 3; }
+                if (dctx.issued[pi].records != (next_tile ? cc.records_next : cc.records_cur)) { printf("jit chain: unit %d staged with the wrong record count\n", blk); return 3; }
+              }
+              const int rcp = check_pieces(dctx.issued, cc.unit_first_piece[blk], cc.unit_first_piece[blk + 1], ocg, nb, fill_base,
+                                           next_tile ? tab_nxt : tab_cur);
+              if (rcp) return rcp;
+            }
+            dma_checked += (long)dctx.issued.size();
+            for (int lane = 0; lane < 64; ++lane)
+              for (int r = 0; r < kAccAll; ++r) acc[((size_t)wave * 64 + lane) * kAccAll + r] = jw.v[(size_t)lane * 256 + 64 + r];
+          }
+        } else
+        for (int blk = 0; blk < t.n_icb; ++blk) {
+          // ---- fill ----
+          fill_block(blk, lds);
           // ---- stream walk per wave ----
           for (int wave = 0; wave < t.waves; ++wave) {
             const int pw = wave % t.pix_waves, ow_ = wave / t.pix_waves;
@@ -351,7 +572,7 @@ static int run(const Case &cs, bool use_jit) {
                 std::vector<int> seen(n_instr, 0);
                 for (const DmaPiece &pcs : dctx.issued) {
                   const uint32_t rel = pcs.m0 - dctx.fill_base;
-                  if (rel % 1024 || (int)(rel / 1024) >= n_instr) { printf("jit dma: bad LDS address\n"); return 3; }
+                  if (rel % 1024 || (int)(rel / 1024) >= n_instr) { printf("jit dma: bad LDS address m0=%u fill_base=%u n_instr=%d nb=%d\n", pcs.m0, dctx.fill_base, n_instr, nb); return 3; }
                   const int i = (int)(rel / 1024);
                   if (i % 8 != ocg % 8) { printf("jit dma: piece %d issued by wave %d\n", i, ocg % 8); return 3; }
                   seen[i]++;
@@ -487,9 +708,9 @@ static int run(const Case &cs, bool use_jit) {
     maxref = std::fmax(maxref, std::fabs(want[i]));
   }
   const double rel = maxerr / std::fmax(1e-6, maxref);
-  printf("%sN%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: tpl=%d S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
+  printf("%s%sN%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: tpl=%d S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
          "groups=%ld recs=%ld recs/group=%.2f dma=%ld rel_err=%.2e\n",
-         use_jit ? "jit " : "", cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.tpl, t.S4, t.G,
+         use_jit ? "jit " : "", use_jit && jp.chained ? "chained " : "", cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.tpl, t.S4, t.G,
          t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes,
          ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, dma_checked, rel);
   if (use_jit && jdma.on && dma_checked == 0) { printf("jit dma: nothing was checked\n"); return 3; }
@@ -527,6 +748,14 @@ int main() {
       {32, 300, 14, 14, 256, 1, 1, 0, 0, 1, 0.95f, 8, 65536, 32},    // 256 output channels, one image per tile: generated code takes one quad per lane, 32 channels per wave
       {16, 400, 7, 7, 384, 1, 1, 0, 0, 1, 0.97f, 8, 65536, 16},    // 384: 48 channels per wave, output rows that are not whole quads
       {16, 10, 4, 4, 300, 1, 1, 0, 0, 1, 0.8f, 8, 65536, 16},    // 300: a ragged last slot range (38 channels per wave, 4 in the last)
+      // chained units over many blocks (small plane budgets): one and two fills in flight (odd C: two), 3x3 and pointwise,
+      // whole images and bands, a tile count that leaves the buffer rotation at every phase
+      {2, 21, 14, 14, 16, 3, 3, 1, 1, 1, 0.8f, 8, 16384},
+      {3, 24, 28, 28, 64, 3, 3, 1, 1, 1, 0.9f, 8, 16384},
+      {5, 33, 14, 14, 32, 1, 1, 0, 0, 1, 0.9f, 8, 8192},
+      {4, 45, 7, 7, 24, 3, 3, 1, 1, 1, 0.85f, 8, 8192},
+      {3, 20, 56, 56, 8, 3, 3, 1, 1, 1, 0.9f, 8, 32768},
+      {9, 37, 7, 7, 64, 1, 1, 0, 0, 1, 0.9f, 8, 4096, 256},
   };
   int bad = 0;
   for (const Case &c : cases) {

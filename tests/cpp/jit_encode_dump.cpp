@@ -85,7 +85,44 @@ int main() {
     snprintf(buf, sizeof buf, "s_add_u32 s%d, s%d, 0x%x", kSPref, kSPref, 0x1000u + 77u * i);
     dump(buf, c);
   }
+  // block-to-block chaining (ChainPlan): counted vmcnt waits, the buffer rotation, the address moves
+  for (int i = 0; i < 64; ++i) {
+    std::vector<uint32_t> c;
+    enc_waitcnt_vm(c, i);
+    snprintf(buf, sizeof buf, "s_waitcnt vmcnt(%d)", i);
+    dump(buf, c);
+    c.clear();
+    const int sa = 44 + (int)rnd(12), sb = 44 + (int)rnd(12), sc = 44 + (int)rnd(12);
+    enc_s_mov(c, sa, sb);
+    snprintf(buf, sizeof buf, "s_mov_b32 s%d, s%d", sa, sb);
+    dump(buf, c);
+    c.clear();
+    const uint32_t lit = 1024u * (1 + rnd(160)) + 1024u * 65u;
+    enc_s_add_u32_lit(c, sa, sb, lit);
+    snprintf(buf, sizeof buf, "s_add_u32 s%d, s%d, 0x%x", sa, sb, lit);
+    dump(buf, c);
+    c.clear();
+    enc_s_sub_u32(c, sa, sb, sc);
+    snprintf(buf, sizeof buf, "s_sub_u32 s%d, s%d, s%d", sa, sb, sc);
+    dump(buf, c);
+    c.clear();
+    enc_s_cmp_lt_u32_lit(c, sa, lit);
+    snprintf(buf, sizeof buf, "s_cmp_lt_u32 s%d, 0x%x", sa, lit);
+    dump(buf, c);
+    c.clear();
+    enc_s_cselect_or_zero(c, sa, sb);
+    snprintf(buf, sizeof buf, "s_cselect_b32 s%d, s%d, 0", sa, sb);
+    dump(buf, c);
+    c.clear();
+    const int vd = 32 + (int)rnd(3), vs = 32 + (int)rnd(3);
+    enc_v_add_u32_s(c, vd, sa, vs);
+    snprintf(buf, sizeof buf, "v_add_u32 v%d, s%d, v%d", vd, sa, vs);
+    dump(buf, c);
+  }
   std::vector<uint32_t> c;
+  enc_barrier(c);
+  dump("s_barrier", c);
+  c.clear();
   enc_exec_all(c);
   dump("s_mov_b64 exec, -1", c);
   c.clear();

@@ -1,8 +1,9 @@
 """WeightAlign's MI355X half without a GPU: the tiling choice and the weight stream built by
 csrc/stream_builder.cpp are walked by a CPU emulation of the tiled kernel's dataflow
 (tests/cpp/emulate_tiled.cpp: LDS planes, lane->quad mapping, bucket walk, accumulator classes,
-shift-and-sum epilogue) and compared with a plain dense convolution on 29 geometries; the same for
-the machine code csrc/jit_codegen.cpp generates, run by an interpreter of its five instruction forms."""
+shift-and-sum epilogue) and compared with a plain dense convolution on 35 geometries; the same for
+the machine code csrc/jit_codegen.cpp generates, run by an interpreter of its instruction forms -- unit by
+unit, and as whole-tile chains (waits, barriers, buffer rotation in code) where the generator chains them."""
 import os
 import subprocess
 
@@ -19,10 +20,14 @@ def test_stream_and_tiling_against_cpu_emulation(tmp_path):
     text = out.stdout.decode()
     assert out.returncode == 0, text
     assert "all cases OK" in text
-    # 29 geometries through the LDS-staged weight stream and again through the code jit_codegen.cpp
+    # 35 geometries through the LDS-staged weight stream and again through the code jit_codegen.cpp
     # generates, interpreted instruction by instruction
-    assert text.count("rel_err=") == 29 + 29
-    assert len([l for l in text.splitlines() if l.startswith("jit ")]) == 29
+    assert text.count("rel_err=") == 35 + 35
+    assert len([l for l in text.splitlines() if l.startswith("jit ")]) == 35
+    # ... a good part of them as chains (one call per tile), several blocks long, with one and two fills in flight
+    chained = [l for l in text.splitlines() if l.startswith("jit chained ")]
+    assert len(chained) >= 15
+    assert sum(1 for l in chained if int(l.split("icb=")[1].split()[0].split("/")[1]) >= 3) >= 4
 
 
 def test_channel_deal_is_a_permutation_and_never_worse(tmp_path):
