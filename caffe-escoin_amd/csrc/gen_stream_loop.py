@@ -618,6 +618,48 @@ def main():
         lines.append("ESC_PX%d_%%=:" % tile)
         lines.append("s_mov_b64 exec, s[32:33]")
         emit_macro(out, "%s_%d" % (mname, tile), lines)
+    # ESC_EPI1SP_<tile>_<r>: pointwise layers whose output rows end in a PARTIAL quad of r = OW % 4 elements
+    # (7 x 7 walked as 1 x 49: twelve quads and one element): whole quads go out as dwordx4 under %[ok], the
+    # row's last quad as dword / dwordx2 / dwordx3 under %[okp].  (The C++ epilogue these layers took before
+    # spends ~60 instructions per channel on address arithmetic and branches over the quad's width.)
+    for tile, base in ((0, ACC_A), (1, ACC_B)):
+        for r in (1, 2, 3):
+            lines = ["s_mov_b64 s[32:33], exec", "s_mov_b64 s[34:35], %[base]"]
+            ng = NACC_TILE // 4
+            for g in range(ng):
+                C0 = base + 4 * g
+                lines += [
+                    "s_bitcmp1_b32 %[flags], 0",
+                    "s_cbranch_scc0 ESC_QB%d_%d_%d_%%=" % (tile, r, g),
+                    "v_readlane_b32 s36, %%[bias], %d" % g,
+                    "s_nop 1",
+                    "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0, C0 + 1, C0, C0 + 1),
+                    "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0 + 2, C0 + 3, C0 + 2, C0 + 3),
+                    "ESC_QB%d_%d_%d_%%=:" % (tile, r, g),
+                    "s_bitcmp1_b32 %[flags], 1",
+                    "s_cbranch_scc0 ESC_QR%d_%d_%d_%%=" % (tile, r, g),
+                ]
+                lines += ["v_max_f32 v%d, 0, v%d" % (C0 + e, C0 + e) for e in range(4)]
+                part = {1: "global_store_dword %%[voff], v%d, s[34:35]" % C0,
+                        2: "global_store_dwordx2 %%[voff], v[%d:%d], s[34:35]" % (C0, C0 + 1),
+                        3: "global_store_dwordx3 %%[voff], v[%d:%d], s[34:35]" % (C0, C0 + 2)}[r]
+                lines += [
+                    "ESC_QR%d_%d_%d_%%=:" % (tile, r, g),
+                    "s_mov_b64 exec, %[ok]",
+                    "global_store_dwordx4 %%[voff], v[%d:%d], s[34:35]%s" % (C0, C0 + 3, STORE_MOD),
+                    "s_mov_b64 exec, %[okp]",
+                    part + STORE_MOD,
+                    "s_mov_b64 exec, s[32:33]",
+                ]
+                if g + 1 < ng:
+                    lines += [
+                        "s_add_u32 s34, s34, %[ostr]",
+                        "s_addc_u32 s35, s35, 0",
+                        "s_cmp_eq_u32 %%[gcount], %d" % (g + 1),
+                        "s_cbranch_scc1 ESC_QX%d_%d_%%=" % (tile, r),
+                    ]
+            lines.append("ESC_QX%d_%d_%%=:" % (tile, r))
+            emit_macro(out, "ESC_EPI1SP_%d_%d" % (tile, r), lines)
     out.write("#define ESC_EPI3S_CLOBBERS \"memory\", \"scc\", \"s32\", \"s33\", \"s34\", \"s35\", \"s36\", \"s37\", \"s38\", \"s39\", ")
     out.write(", ".join('\"v%d\"' % i for i in range(ACC_A, 256)))
     out.write("\n")

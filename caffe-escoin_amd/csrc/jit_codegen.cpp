@@ -27,7 +27,8 @@ int dma_period(int qpc, int max_period, double slack, int *padded) {
 Options options_from_env() {
   Options o;
   if (const char *e = getenv("ESCOIN_JIT_DEPTH")) o.depth = std::max(1, std::min(2, atoi(e)));
-  if (const char *e = getenv("ESCOIN_JIT_DEPTH1")) o.depth_one_tile = std::max(1, std::min(5, atoi(e)));
+  if (const char *e = getenv("ESCOIN_JIT_DEPTH1")) o.depth_one_tile = std::max(1, std::min(13, atoi(e)));
+  if (const char *e = getenv("ESCOIN_JIT_HI_SETS")) o.hi_sets = std::max(0, std::min(24, atoi(e)));
   if (const char *e = getenv("ESCOIN_JIT_HOIST")) o.hoist_weight = atoi(e) != 0;
   if (const char *e = getenv("ESCOIN_JIT_PRIO_ROWS")) o.prio_rows = std::max(0, atoi(e));
   if (const char *e = getenv("ESCOIN_JIT_PRIO_WAVES")) o.prio_waves = std::max(0, atoi(e));
@@ -104,14 +105,21 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
   // ahead.  A row of such a layer (pointwise, 95 % sparse) carries one or two nonzeros -- 10-25 cycles of
   // FMAs -- and an LDS read takes well over a hundred to land: two rows of read-ahead left the walk
   // waiting for LDS latency on every row.
-  const int n_sets = opt.one_tile > 0 ? 2 * kInSets : kInSets;
+  // ... and where tile B exists but holds no rows (a small image walked one or a few to a workgroup), its 96
+  // accumulator registers are free as well: 24 more quads (opt.hi_sets), rows read up to thirteen ahead -- LDS
+  // counts at most 15 operations in flight, and the plane DMA's table reads share that count
+  const int n_sets = opt.one_tile > 0 ? 2 * kInSets + opt.hi_sets : kInSets;
   const int set_regs = opt.one_tile > 0 ? 4 : 8;
-  const int depth = opt.one_tile > 0 ? std::max(1, std::min(opt.depth_one_tile, n_sets - 1)) : opt.depth;
+  const int depth = opt.one_tile > 0 ? std::max(1, std::min(opt.depth_one_tile, std::min(13, n_sets - 1))) : opt.depth;
+  auto set_base = [&](int k) {
+    const int sidx = k % n_sets;
+    return opt.one_tile > 0 && sidx >= 2 * kInSets ? kAccB + 4 * (sidx - 2 * kInSets) : kVIn0 + set_regs * sidx;
+  };
   Lds lds{c, 0, 0, opt.ablate};
   std::vector<int> row_id(n, -1);       // issue id of a row's second read
   auto issue = [&](int k) {
     if (opt.ablate & 2) return;
-    const int base = kVIn0 + set_regs * (k % n_sets);
+    const int base = set_base(k);
     enc_ds_read_b128(c, base, kVAddrA, rows[k].lds_off);
     lds.issue();
     if (opt.one_tile) { row_id[k] = lds.issued - 1; return; }
@@ -181,7 +189,7 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     if (opt.ablate & 2) enc_waitcnt_lgkm(c, 0);
     else lds.wait_for(row_id[k]);
     issue_pieces(k);
-    const int xa = kVIn0 + set_regs * (k % n_sets), xb = xa + 4;
+    const int xa = set_base(k), xb = xa + 4;
     for (int j = first_of_row[k]; j < first_of_row[k + 1]; ++j) {
       if (opt.ablate & 4) {
       } else if (opt.hoist_weight) {
@@ -329,6 +337,9 @@ Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std:
   // accumulators hold channels 24 .. 47 of the wave
   if (t.tpl == 1 || (t.pix_waves == 1 && t.tr * t.nseg <= t.rows_per_slab && opt.one_tile >= 0)) opt.one_tile = 1;
   else opt.one_tile = 0;
+  // tile B's accumulators as input registers: only where they hold nothing (two quads per lane in the tiling,
+  // none of tile B's rows in the image) -- with one quad per lane they carry channels 24 .. 47
+  if (!(opt.one_tile && t.tpl == 2)) opt.hi_sets = 0;
   // the channel deal (once: both passes below generate code for the same deal)
   std::vector<uint32_t> chan;
   chan.reserve((size_t)g.group * t.n_ocg * t.G);

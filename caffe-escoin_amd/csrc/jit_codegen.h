@@ -195,7 +195,8 @@ constexpr int kVPrefDead = 62, kVPrefLane = 63, kSPref = 50;
 
 struct Options {
   int depth = 2;          // rows read ahead (1 or 2; three input sets allow 2)
-  int depth_one_tile = 5; // ... in code without a tile B (six single-quad sets: up to 5)
+  int depth_one_tile = 5; // ... in code without a tile B (six single-quad sets: up to 5; with hi_sets up to 13)
+  int hi_sets = 24;       // extra single-quad input sets in v[160:255] (tile B's accumulators, where tile B has no rows)
   int hoist_weight = 1;   // s_mov of record j+1 issued before the FMAs of record j
   int prio_rows = 0;      // > 0: s_setprio alternates 1 / 0 every this many rows (0: never) ...
   int prio_waves = 0;     // ... in the units of the first this many waves of a workgroup (0: every unit): the

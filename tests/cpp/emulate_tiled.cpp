@@ -196,7 +196,8 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
     if ((d0 & 0xFFFF0000u) == 0xD9FE0000u) {   // ds_read_b128
       const unsigned off = d0 & 0xFFFFu;
       const int vdst = (int)(d1 >> 24), vaddr = (int)(d1 & 0xFF);
-      if ((d1 & 0x00FFFF00u) != 0 || (vaddr != 32 && vaddr != 33) || vdst < 36 || vdst + 3 > 59) { printf("jit: bad ds_read operands\n"); return 3; }
+      // (destinations: the input sets v[36:59]; code without a tile B may also use tile B's accumulators v[160:255])
+      if ((d1 & 0x00FFFF00u) != 0 || (vaddr != 32 && vaddr != 33) || vdst < 36 || (vdst + 3 > 59 && (vdst < 160 || vdst + 3 > 255 || vaddr != 32))) { printf("jit: bad ds_read operands\n"); return 3; }
       if (is_pending(vdst)) { printf("jit: read into a register with a read pending\n"); return 3; }
       PendingRead r;
       r.vdst = vdst;
@@ -287,7 +288,7 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
     if ((d0 & 0xFFFFFF00u) == 0xD3B04000u) {   // v_pk_fma_f32 acc, s[w:w+1], v[x:x+1], acc op_sel_hi:[0,1,1]
       const int acc = (int)(d0 & 0xFF), sw = (int)(d1 & 0x1FF);
       const int x = (int)((d1 >> 9) & 0x1FF) - 256, acc2 = (int)((d1 >> 18) & 0x1FF) - 256;
-      if (acc != acc2 || acc < 64 || acc > 254 || (acc & 1) || x < 36 || x > 58 || sw > 101 || (d1 >> 27) != 2u) { printf("jit: bad v_pk_fma_f32 operands\n"); return 3; }
+      if (acc != acc2 || acc < 64 || acc > 254 || (acc & 1) || x < 36 || (x > 58 && (x < 160 || x > 254 || acc >= 160)) || sw > 101 || (d1 >> 27) != 2u) { printf("jit: bad v_pk_fma_f32 operands\n"); return 3; }
       if (is_pending(x) || is_pending(x + 1)) { printf("jit: FMA reads v%d before its LDS read was waited for\n", x); return 3; }
       float wv;
       std::memcpy(&wv, &sreg[sw], 4);
@@ -341,6 +342,8 @@ static int run(const Case &cs, bool use_jit) {
     jo.depth = 1 + (cs.N & 1);            // both read-ahead depths and both weight placements get exercised
     jo.hoist_weight = (cs.C >> 1) & 1;
     jo.prio_rows = (cs.M & 1) ? 2 : 0;
+    jo.hi_sets = (cs.N & 1) ? 24 : 0;     // (used only by code without a tile B: deeper read-ahead through tile B's registers)
+    jo.depth_one_tile = (cs.N & 1) ? 5 + cs.N % 9 : 5;
     // plane DMA from inside the code wherever one wave owns an oc-group (whatever the table's size: the
     // product bounds it, the emulation does not need to)
     if (t.pix_waves == 1 && t.waves == 8) {

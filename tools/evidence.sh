@@ -6,21 +6,25 @@
 #  * in-kernel stamp profile (ESCOIN_PROF=1 on the -DESCOIN_ABLATIONS build) of the four ResNet shapes and
 #    three GoogLeNet sizes, HBM-cold (four rotating blob pairs)
 #  * ESCOIN_JIT_ABL ablation table per ResNet shape (timing only; results are wrong for != 0)
+#   EVIDENCE_ONLY=stamp: the stamp profile only
 set -u
 TAG=${1:-r04}
 ABL=${2:-$PWD/caffe-escoin_amd/libescoin_abl.so}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
+if [ "${EVIDENCE_ONLY:-}" != "stamp" ]; then
 ( cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o probe_valu_rate probe_valu_rate.hip && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o probe_mixload probe_mixload.hip ) > $OUT/probe_build.log 2>&1
 timeout -k 10 120 tools/probes/probe_valu_rate > $OUT/probe_valu_rate.txt 2>&1
 timeout -k 10 180 tools/probes/probe_mixload > $OUT/probe_mixload.txt 2>&1
 echo probes done
+fi
 for L in res2 res3 res4 res5 goog0 goog5 goog13 goog25 goog33 goog37; do
   ESCOIN_LIB=$ABL ESCOIN_PROF=1 ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 2 > $OUT/stamp_$L.log 2>&1
   ESCOIN_LIB=$ABL ESCOIN_VERBOSE=1 ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 200 > $OUT/time_abl_$L.log 2>&1
   ESCOIN_VERBOSE=1 ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 200 > $OUT/time_$L.log 2>&1
   echo "stamp $L done"
 done
+[ "${EVIDENCE_ONLY:-}" = "stamp" ] && exit 0
 for L in res2 res3 res4 res5; do
   for a in 0 1 2 4 8 3 7; do
     echo "ABL=$a $(ESCOIN_JIT_ABL=$a ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 100 2>&1 | tail -1)" >> $OUT/jit_abl_$L.txt

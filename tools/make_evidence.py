@@ -18,6 +18,8 @@ def last(path, pat):
 
 
 for name in ("probe_valu_rate", "probe_mixload"):
+    if not os.path.exists(os.path.join(src, name + ".txt")):
+        continue
     with open(os.path.join(out, "%s_%s.txt" % (tag, name)), "w") as f:
         f.write("# tools/probes/%s.hip on one MI355X (tools/evidence.sh), raw output\n" % name)
         f.write(open(os.path.join(src, name + ".txt")).read())
@@ -74,6 +76,9 @@ with open(os.path.join(out, "%s_stamp_profile.md" % tag), "w") as f:
         parts = [c("tile misc") * scale, c("tab+zero") * scale, tops * scale, c("loop") * scale, c("epilogue") * scale, ka - us]
         f.write("| %s | %s | %.1f | %.1f |\n" % (names[L], " | ".join("%.1f" % x for x in parts), sum(parts), kp))
 
+if not os.path.exists(os.path.join(src, "jit_abl_res2.txt")):
+    print("written (stamp profile only)")
+    sys.exit(0)
 with open(os.path.join(out, "%s_jit_ablations.md" % tag), "w") as f:
     f.write("# Timing-only ablations of the generated-code kernel, ResNet-50 3x3 shapes @90 %%, batch 256, one MI355X, %s\n\n" % tag)
     f.write("`tools/evidence.sh`: `tools/one_layer.py <layer> 100` (four rotating blob pairs: every launch reads from HBM), us per launch,\n"
