@@ -55,6 +55,12 @@ struct DenseArgs {
   int vec_out;                             // OH*OW % 4 == 0 and top 16-byte aligned: 16-byte stores through LDS
   unsigned long long group_mask;           // conv groups this launch covers (all ones: every group)
   int abl;                                 // ESCOIN_ABLATIONS builds: timing experiments (wrong results)
+  // stream-K (STREAMK instantiations): every workgroup takes an equal, contiguous run of (tile, k-step) units;
+  // a tile cut by a run boundary is finished by the workgroup holding its last k-steps, which adds the others'
+  // partial accumulators from `sk_ws` ([workgroup][wave][16 quads][64 lanes] floats x 4) once their `sk_flag`
+  // words (zeroed by the launch function before every launch) carry 1
+  float *sk_ws;
+  unsigned *sk_flag;     // [0 .. gridDim.x): published flags; [gridDim.x]: set when a bounded spin gave up
 };
 
 __device__ __forceinline__ int a_swizzle(int row, int chunk) { return row * kBK + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -85,7 +91,9 @@ __device__ __forceinline__ u32x4d make_rsrc(const void *p, unsigned bytes) {
   return r;
 }
 
-template <int WROWS, bool POINTWISE4>
+typedef unsigned __attribute__((address_space(1))) gu32;
+
+template <int WROWS, bool POINTWISE4, bool STREAMK = false>
 __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) {
   constexpr int BM = 64 * WROWS;
   constexpr int WCOLS = 4 / WROWS;           // waves along the pixel axis
@@ -191,22 +199,41 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
   };
 
   f32x16 acc[2][NB];
-  long tile = blockIdx.x;
-  if (tile >= n_tiles) return;
+  // Work of this workgroup.  Tile mode: tiles blockIdx.x, + gridDim.x, ..., every k-step of each.  Stream-K:
+  // units [u0, u1) of the (tile, k-step) sequence -- a run starts and ends anywhere in a tile.  The run's tiles are
+  // walked LAST TO FIRST: the cut tile at the run's end (whose partial sums another workgroup waits for) comes
+  // first and is published at once, the cut tile at its start (which waits for the previous workgroup's partial
+  // sums) last -- walked first to last, every workgroup would wait for its predecessor's whole run.
+  const long U = n_tiles * nk;
+  const long sk_q = STREAMK ? (U + gridDim.x - 1) / gridDim.x : 0;
+  const long u0 = STREAMK ? (long)blockIdx.x * sk_q : 0;
+  const long u1 = STREAMK ? min(U, u0 + sk_q) : 0;
+  if (STREAMK && u0 >= u1) return;
+  const long t0 = STREAMK ? u0 / nk : 0, t1 = STREAMK ? (u1 - 1) / nk : 0;
+  auto seg_lo = [&](long t) { return STREAMK && t == t0 ? (int)(u0 - t0 * nk) : 0; };
+  auto seg_hi = [&](long t) { return STREAMK && t == t1 ? (int)(u1 - t1 * nk) : nk; };
+  const long tile_step = STREAMK ? -1 : (long)gridDim.x;
+  auto in_run = [&](long t) { return STREAMK ? t >= t0 : t < n_tiles; };
+  long tile = STREAMK ? t1 : (long)blockIdx.x;
+  if (!in_run(tile)) return;
   fetch_setup(tile);
-  fetch(0, 0);
-  long f_tile = tile;     // tile of the step being fetched next
-  int f_k = 1;            // ... and its k-step
-  if (f_k == nk) { f_k = 0; f_tile += gridDim.x; if (f_tile < n_tiles) fetch_setup(f_tile); }
+  fetch(seg_lo(tile), 0);
+  long f_tile = tile;             // tile of the step being fetched next
+  int f_k = seg_lo(tile) + 1;     // ... and its k-step
+  if (f_k == seg_hi(f_tile)) {
+    f_tile += tile_step;
+    if (in_run(f_tile)) { f_k = seg_lo(f_tile); fetch_setup(f_tile); }
+  }
   int buf = 0;
-  for (; tile < n_tiles; tile += gridDim.x) {
+  for (; in_run(tile); tile += tile_step) {
     int cg, m0, p0;
     tile_coords(tile, cg, m0, p0);
+    const int k_lo = seg_lo(tile), k_hi = seg_hi(tile);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x16{0};
-    for (int ks = 0; ks < nk; ++ks, buf ^= 1) {
+    for (int ks = k_lo; ks < k_hi; ++ks, buf ^= 1) {
       // this wave's pieces of the step have landed (and the stores of the last epilogue are out) ...
 #ifdef ESCOIN_ABLATIONS
       if (!(a.abl & 1))     // ESCOIN_DENSE_ABL: 1 no wait for the operands, 2 no operand traffic, 4 no MFMAs
@@ -216,12 +243,11 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
 #ifdef ESCOIN_ABLATIONS
       if (!(a.abl & 2))
 #endif
-      if (f_tile < n_tiles) {
+      if (in_run(f_tile)) {
         fetch(f_k, buf ^ 1);
-        if (++f_k == nk) {
-          f_k = 0;
-          f_tile += gridDim.x;
-          if (f_tile < n_tiles) fetch_setup(f_tile);
+        if (++f_k == seg_hi(f_tile)) {
+          f_tile += tile_step;
+          if (in_run(f_tile)) { f_k = seg_lo(f_tile); fetch_setup(f_tile); }
         }
       }
       // fragments of k-group kg + 1 are read while the MFMAs of k-group kg run
@@ -257,6 +283,67 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
             acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], fb[s][t][j], acc[0][j], 0, 0, 0);
             acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], fb[s][t][j], acc[1][j], 0, 0, 0);
           }
+        }
+      }
+    }
+    if (STREAMK) {
+      // the lane's accumulators as 16 * NB quads: quad (i, j, r4) = acc[i][j][4 r4 .. 4 r4 + 3]
+      constexpr int kQuads = 2 * NB * 4;
+      constexpr size_t kWsPerWg = (size_t)4 * 16 * 64 * 4;     // floats: 4 waves x 16 quads x 64 lanes x 4
+      if (k_hi < nk) {
+        // a run that ends inside a tile: hand the partial sums to the workgroup holding the tile's last k-steps.
+        // Write-through stores (sc1: visible beyond this XCD's L2 once they have drained), every storing wave
+        // drains, the workgroup meets, ONE lane publishes (cdna_hip_programming.md Guideline 16, R1).
+        float *ws = a.sk_ws + (size_t)blockIdx.x * kWsPerWg + (size_t)wave * (16 * 64 * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int qd = (i * NB + j) * 4 + r4;
+              typedef float f32x4 __attribute__((ext_vector_type(4)));
+              const f32x4 v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+              float *dst = ws + (size_t)(qd * 64 + lane) * 4;
+              asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gu32 *)(a.sk_flag + blockIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)kQuads;
+        continue;     // (the run's last tile, walked first: the others are whole, or finished below)
+      }
+      if (k_lo > 0) {
+        // this workgroup finishes a tile others began: add their partial sums, nearest run first (a fixed
+        // order: results do not depend on timing).  The runs covering the tile's earlier units are those of
+        // workgroups blockIdx.x - 1, - 2, ... down to the one holding the tile's first unit.
+        const long tile_lo = tile * (long)nk;
+        for (long w = (long)blockIdx.x - 1; w >= 0 && (w + 1) * sk_q > tile_lo; --w) {
+          if (wave == 0) {
+            // ONE wave polls ONE word, relaxed, bounded (a stuck launch must end: the give-up word makes the host fail)
+            unsigned spins = 0;
+            while (__hip_atomic_load((gu32 *)(a.sk_flag + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > (1u << 24)) {
+                if (lane == 0) __hip_atomic_store((gu32 *)(a.sk_flag + gridDim.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
+          const float *ws = a.sk_ws + (size_t)w * kWsPerWg + (size_t)wave * (16 * 64 * 4);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const int qd = (i * NB + j) * 4 + r4;
+                const float4 v = *reinterpret_cast<const float4 *>(ws + (size_t)(qd * 64 + lane) * 4);
+                acc[i][j][4 * r4] += v.x; acc[i][j][4 * r4 + 1] += v.y; acc[i][j][4 * r4 + 2] += v.z; acc[i][j][4 * r4 + 3] += v.w;
+              }
         }
       }
     }
@@ -434,14 +521,55 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   const long tiles = (long)a.n_ptiles * a.n_mtiles * a.n_groups;
   // persistent: two 4-wave workgroups per CU walk the tiles
   const long slots = 2l * dense_device_cus();
-  dim3 grid((unsigned)std::min<long>(tiles, slots), 1, 1);
-  if (bm == 64) {
-    if (vec_b) hipLaunchKernelGGL((escoin_dense_mfma_kernel<1, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((escoin_dense_mfma_kernel<1, false>), grid, dim3(256), 0, stream, a);
-  } else {
-    if (vec_b) hipLaunchKernelGGL((escoin_dense_mfma_kernel<2, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((escoin_dense_mfma_kernel<2, false>), grid, dim3(256), 0, stream, a);
+  // Stream-K where whole tiles leave slots idle: 784 tiles on 512 slots are two rounds at 77 % occupancy, 392 tiles
+  // one round at 77 % (the ResNet-50 chain's 14 x 14 and 7 x 7 1x1 layers; hipBLASLt splits K on exactly these
+  // shapes and led by 13-24 %, profiles/r03_dense_vs_libraries.md).  Every workgroup then takes an equal run of
+  // (tile, k-step) units and the tiles cut by run boundaries are fixed up in the launch (kernel, STREAMK).
+  // Taken when the tile schedule would waste more than 15 % of the slots and a tile has at least eight k-steps
+  // (same-call A/B on the chain, profiles/r04_dense_streamk.md: 784 tiles -13 %, 392 tiles -16 %, 1568 tiles -4..-5 %;
+  // at 87.5 % occupancy -- 3136 tiles -- the fix-up costs more than the idle slots: +4..6 %).
+  // ESCOIN_DENSE_STREAMK = 0 / 1 forces it off / on.
+  static const int sk_env = getenv("ESCOIN_DENSE_STREAMK") ? atoi(getenv("ESCOIN_DENSE_STREAMK")) : -1;
+  const long nk = (g.kdim + kBK - 1) / kBK;
+  const long rounds = (tiles + slots - 1) / slots;
+  const double occupancy = (double)tiles / (double)(rounds * slots);
+  // (pointwise layers only: with the 4-byte gathers of the other operand path the stride-2 1x1 layer res5a_branch1
+  //  went from 581 to 629 us)
+  bool streamk = sk_env >= 0 ? sk_env != 0 : (vec_b && occupancy < 0.85 && nk >= 8 && tiles * nk >= 4 * slots);
+  if (tiles * nk < slots) streamk = false;
+  const long n_wg = streamk ? slots : std::min<long>(tiles, slots);
+  a.sk_ws = nullptr;
+  a.sk_flag = nullptr;
+  if (streamk) {
+    const size_t ws_bytes = (size_t)n_wg * 4 * 16 * 64 * 4 * sizeof(float);
+    const size_t flag_bytes = ((size_t)(n_wg + 1) * 4 + 15) / 16 * 16;
+    if (p->sk_ws_bytes < ws_bytes + flag_bytes) {
+      if (p->d_sk_ws) (void)hipFree(p->d_sk_ws);
+      p->d_sk_ws = nullptr;
+      p->sk_ws_bytes = 0;
+      // (the flag block leads: it is what the memset below clears, from the allocation's start, a multiple of 16 bytes)
+      ESCOIN_HIP_TRY(hipMalloc(&p->d_sk_ws, ws_bytes + flag_bytes));
+      p->sk_ws_bytes = ws_bytes + flag_bytes;
+    }
+    a.sk_flag = reinterpret_cast<unsigned *>(p->d_sk_ws);
+    a.sk_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(p->d_sk_ws) + flag_bytes);
+    ESCOIN_HIP_TRY(hipMemsetAsync(a.sk_flag, 0, flag_bytes, stream));
+    p->sk_flag_words = (int)n_wg + 1;
   }
+  dim3 grid((unsigned)n_wg, 1, 1);
+#define ESC_DENSE_LAUNCH(WR, PW)                                                                                   \
+  do {                                                                                                             \
+    if (streamk) hipLaunchKernelGGL((escoin_dense_mfma_kernel<WR, PW, true>), grid, dim3(256), 0, stream, a);       \
+    else hipLaunchKernelGGL((escoin_dense_mfma_kernel<WR, PW, false>), grid, dim3(256), 0, stream, a);             \
+  } while (0)
+  if (bm == 64) {
+    if (vec_b) ESC_DENSE_LAUNCH(1, true);
+    else ESC_DENSE_LAUNCH(1, false);
+  } else {
+    if (vec_b) ESC_DENSE_LAUNCH(2, true);
+    else ESC_DENSE_LAUNCH(2, false);
+  }
+#undef ESC_DENSE_LAUNCH
   ESCOIN_HIP_TRY(hipGetLastError());
   return ESCOIN_OK;
 }

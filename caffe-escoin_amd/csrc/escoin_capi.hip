@@ -76,6 +76,10 @@ static void free_device(escoin_plan *p) {
   p->d_dense_w = nullptr;
   if (p->d_ktab) (void)hipFree(p->d_ktab);
   p->d_ktab = nullptr;
+  if (p->d_sk_ws) (void)hipFree(p->d_sk_ws);
+  p->d_sk_ws = nullptr;
+  p->sk_ws_bytes = 0;
+  p->sk_flag_words = 0;
   p->d_rowptr = p->d_taps = nullptr;
   p->d_vals = nullptr;
   p->device_bytes = 0;
@@ -551,6 +555,16 @@ long escoin_plan_stat(const escoin_plan *p, const char *key) {
   if (!strcmp(key, "jit_records")) return p->tiled.jit ? p->tiled.jit_records : 0;
   if (!strcmp(key, "lds_bytes")) return p->tiled.enabled ? (long)p->tiled.lds_bytes : 0;
   if (!strcmp(key, "workgroup_columns")) return p->tiled.enabled ? p->tiled.tiling.n_ocblk : 0;
+  if (!strcmp(key, "streamk_gave_up")) {
+    // dense kernel, stream-K launches: 1 if a workgroup's bounded wait for another one's partial sums ran out in
+    // the last launch (its results are then wrong); synchronises with the device.  0 for plans that never split K.
+    if (!p->d_sk_ws || p->sk_flag_words < 1) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, static_cast<const unsigned *>(p->d_sk_ws) + (p->sk_flag_words - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(ESCOIN_EHIP, "streamk_gave_up: device read failed");
+    return (long)v;
+  }
+  if (!strcmp(key, "streamk")) return p->d_sk_ws ? 1 : 0;
   if (!strcmp(key, "kernel_choice")) {
     if (!p->aligned) return fail(ESCOIN_ESTATE, "kernel_choice before weight_align / set_csr");
     if (p->use_dense) return ESCOIN_KERNEL_DENSE;

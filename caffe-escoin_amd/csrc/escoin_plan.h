@@ -111,6 +111,12 @@ struct escoin_plan {
   int dense_threshold_pct = -1;   // option "dense_threshold_pct" (-1: the measured default)
   int stream_stores = -1;         // option "stream_stores": pointwise layers write the top blob with non-temporal stores (1), never (0), by size (-1)
 
+  // stream-K workspace of the dense kernel (dense_mfma.hip): flag words, then the partial accumulators; grown on
+  // demand at launch (a plan belongs to one host thread and one stream at a time, like a Caffe layer)
+  mutable void *d_sk_ws = nullptr;
+  mutable size_t sk_ws_bytes = 0;
+  mutable int sk_flag_words = 0;
+
   // LOWERED_SPARSE comparator (sconv_lowered.hip): column buffer, grown on demand
   float *d_col = nullptr;
   size_t col_bytes = 0;

@@ -810,3 +810,97 @@ def test_randomised_pointwise_layers_with_many_output_channels(pkg, oracle, synt
         plan.close()
         assert rel_err(got, want) <= TOL, "%s %s: %g (%s)" % (s.name, (N, C, H, W, M, sp, relu), rel_err(got, want), info)
     assert tpl1 >= 4, tpl1        # some of them must have taken one quad per lane
+
+
+def test_dense_stream_k_fixup(pkg, oracle, synth, torch_cuda):
+    """The dense MFMA kernel splits K across workgroups (stream-K) where whole output tiles would leave more than
+    10 % of its 512 slots idle -- the ResNet-50 chain's 14 x 14 and 7 x 7 1x1 layers (784 / 392 tiles) -- and fixes
+    the cut tiles up inside the launch (partial sums handed over write-through, flags, agent-scope acquire).  All N
+    images against the generic kernel (bit-exact to the oracle) on the device, image 0 / N-1 against the oracle;
+    pointwise and gathered (3x3) operand paths, ragged tile edges, repeated launches (the flags are re-armed)."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    cases = [synth.shape("res5_2a_like", 256, 2048, 7, 7, 512, 1, bias=False, sparsity=0.0),
+             synth.shape("res4_2a_like", 256, 1024, 14, 14, 256, 1, bias=True, sparsity=0.0),
+             synth.shape("res4_3x3_dense", 256, 256, 14, 14, 256, 3, pad=1, bias=False, sparsity=0.0),
+             synth.shape("ragged", 80, 320, 13, 13, 200, 1, bias=True, sparsity=0.0)]
+    for k, s in enumerate(cases):
+        w = (synth.pruned_weights(s, 900 + k) * np.float32(0.05)).astype(np.float32)
+        b = synth.bias_vector(s, 950 + k)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(970 + k)
+        x = torch.rand((s.N, s.C, s.H, s.W), device=dev, generator=gen) * 2 - 1
+        bd = torch.from_numpy(b).to(dev) if b is not None else None
+        ref_plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=True), kernel=pkg.KERNEL_GENERIC)
+        ref_plan.weight_align(w)
+        ref = ref_plan.forward(x, bd)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=True), kernel=pkg.KERNEL_DENSE)
+        plan.weight_align(w)
+        for rep in range(3):
+            top = plan.forward(x, bd)
+            torch.cuda.synchronize()
+            if s.KH == 1:
+                assert plan.stat("streamk") == 1, s.name             # the schedule this test is about
+            # (the 3x3 case runs whole tiles unless ESCOIN_DENSE_STREAMK=1 forces the split: its operand path gathers)
+            assert plan.stat("streamk_gave_up") == 0, s.name
+            scale = max(1e-6, float(ref.abs().max()))
+            err = float((top - ref).abs().max()) / scale
+            assert err <= TOL, "%s launch %d: all %d images vs the generic kernel: %g" % (s.name, rep, s.N, err)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, group=s.group)
+        idx = torch.tensor([0, s.N - 1], device=dev)
+        want = oracle.conv_forward(g, x[idx].cpu().numpy(), w, b, relu=True, gate=False, threads=2)
+        assert rel_err(top[idx].cpu().numpy(), want) <= TOL, s.name
+        # a partial batch changes the tile count: another cut, the same numbers
+        n2 = s.N // 2 + 3
+        top2 = plan.forward(x[:n2].contiguous(), bd)
+        torch.cuda.synchronize()
+        assert float((top2 - ref[:n2]).abs().max()) / scale <= TOL, s.name
+        assert plan.stat("streamk_gave_up") == 0
+        plan.close()
+        ref_plan.close()
+
+
+def test_kernel_auto_follows_the_measured_crossover(pkg, synth, torch_cuda):
+    """What KERNEL_AUTO resolves to, per BASELINE shape (profiles/r04_crossover.md): generated code at every point of
+    the 50-95 % sparsity sweep of the ResNet-50, AlexNet and GoogLeNet sets (it is ahead of the stream kernel and of
+    the dense kernel at each of them); the dense MFMA kernel for unpruned layers; above 50 % density whatever the
+    two-kernel cost model says (res2 stays sparse down to 10 % sparsity, AlexNet conv3 goes dense at 40 %); layers the
+    tiled kernels do not cover (stride 2) go dense above 4 % density, to the generic kernel below."""
+    gl = synth.googlenet_1x1(N=256)
+    layers = synth.resnet50_3x3(N=256) + synth.alexnet(N=128) + [gl[0], gl[1], gl[5], gl[9], gl[25], gl[33], gl[37]]
+    for s in layers:
+        for sp in (0.5, 0.6, 0.7, 0.8, 0.9, 0.95):
+            ss = s._replace(sparsity=sp, N=2)
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(ss), tiling_batch=s.N)
+            plan.weight_align(synth.pruned_weights(ss, 3))
+            assert plan.stat("kernel_choice") == pkg.KERNEL_JIT, (s.name, sp, plan.kernel_name)
+            plan.close()
+        ss = s._replace(sparsity=0.0, N=2)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(ss), tiling_batch=s.N)
+        plan.weight_align(synth.pruned_weights(ss, 3))
+        assert plan.stat("kernel_choice") == pkg.KERNEL_DENSE, (s.name, plan.kernel_name)
+        plan.close()
+    # above the 50 % density cut the model decides, shape by shape
+    def choice(s, sp):
+        ss = s._replace(sparsity=sp, N=2)
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(ss), tiling_batch=s.N)
+        plan.weight_align(synth.pruned_weights(ss, 3))
+        c = plan.stat("kernel_choice")
+        plan.close()
+        return c
+    rn, al = synth.resnet50_3x3(N=256), synth.alexnet(N=128)
+    assert choice(rn[0], 0.2) == pkg.KERNEL_JIT          # res2: 607 us against 783 dense
+    assert choice(rn[2], 0.3) == pkg.KERNEL_JIT          # res4: 605 against 692
+    assert choice(al[1], 0.4) == pkg.KERNEL_DENSE        # AlexNet conv3: 409 against 380
+    assert choice(gl[5], 0.3) == pkg.KERNEL_DENSE        # inception_3b 256@28x28 -> 128: 174 against 143
+    # stride 2 (ResNet-50's res3a_branch2a, pruned): no tiled kernel -- dense above 4 % density, generic below
+    s2 = synth.shape("res3a_branch2a", 2, 256, 56, 56, 128, 1, stride=2, bias=False, sparsity=0.9)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s2), tiling_batch=256)
+    plan.weight_align(synth.pruned_weights(s2, 3))
+    assert plan.stat("kernel_choice") == pkg.KERNEL_DENSE, plan.kernel_name
+    plan.close()
+    s3 = s2._replace(sparsity=0.98)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s3), tiling_batch=256)
+    plan.weight_align(synth.pruned_weights(s3, 3))
+    assert plan.stat("kernel_choice") == pkg.KERNEL_GENERIC, plan.kernel_name
+    plan.close()
