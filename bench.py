@@ -587,6 +587,9 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
                 "launches_per_step": dom["launches"],
                 # per-launch events in `sampled_steps` of the timed steps; one event costs `event_us`
                 # (sampled minus other steps, per launch), already taken off every duration here
+                # (the corrected per-launch durations must add up to a step without events: a check of the
+                #  correction, not a tunable -- bench lines seen so far sit within 2 % of 1)
+                "launch_sum_over_step": round(sum(layer_ms) / max(1e-9, ms_plain), 4),
                 "events": {"sampled_steps": len(sampled), "of": args.steps, "event_us": round(event_ms * 1e3, 2),
                            "ms_per_step_sampled": round(ms_sampled, 4), "ms_per_step_other": round(ms_plain, 4)},
                 "instantiations": {k: {"launches_per_step": v["launches"],

@@ -349,13 +349,50 @@ Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std:
     chan.insert(chan.end(), sl.begin(), sl.end());
   }
   size_t max_unit = 0;
-  Program p = build_pass(g, t, rowptr, colidx, values, opt, 0, &max_unit, chan);
-  if (!opt.prefetch || p.overflow) return p;
-  // every unit carries the same number of touches: enough for the longest unit (its own touches included)
+  if (!opt.prefetch) return build_pass(g, t, rowptr, colidx, values, opt, 0, &max_unit, chan);
+  // Every unit carries the same number of code touches: enough for the longest unit, its own touches included.
+  // The longest unit's size comes from an upper bound on its instruction bytes (a pass of its own over the
+  // nonzeros, no code emitted: round 3 generated every layer twice to learn it) -- at worst one touch too many.
+  size_t bound = 0;
+  {
+    const int rows_per_blk = t.icb * g.KH;
+    std::vector<uint32_t> row_mark(rows_per_blk, 0u);
+    uint32_t stamp = 0;
+    const size_t pieces_per_unit = opt.dma.on ? (size_t)(((long)t.icb * opt.dma.qpc + 63) / 64 + opt.dma.waves - 1) / opt.dma.waves : 0;
+    for (int cg = 0; cg < g.group; ++cg)
+      for (int ocg = 0; ocg < t.n_ocg; ++ocg) {
+        std::vector<size_t> recs(t.n_icb, 0), nrows(t.n_icb, 0);
+        for (int blk = 0; blk < t.n_icb; ++blk) {
+          ++stamp;
+          const int ic_lo = blk * t.icb, ic_hi = std::min(g.Cg, ic_lo + t.icb);
+          for (int gl = 0; gl < t.G && ocg * t.G + gl < g.Mg; ++gl) {
+            const int m = (int)chan[((size_t)cg * t.n_ocg + ocg) * t.G + gl];
+            // (columns ascend within a CSR row: the block's nonzeros are one contiguous run)
+            const int *b = colidx[cg].data() + rowptr[cg][m], *e = colidx[cg].data() + rowptr[cg][m + 1];
+            const int *lo = std::lower_bound(b, e, ic_lo * g.KH * g.KW), *hi = std::lower_bound(lo, e, ic_hi * g.KH * g.KW);
+            recs[blk] += (size_t)(hi - lo);
+            for (const int *c = lo; c < hi; ++c) {
+              const int r = (*c / g.KW) - ic_lo * g.KH;      // (ic - ic_lo) * KH + kr
+              if (row_mark[r] != stamp) { row_mark[r] = stamp; ++nrows[blk]; }
+            }
+          }
+          // bytes: per row two reads and a wait (+ a priority switch), per nonzero a move and four FMAs, per piece
+          // table read, wait, M0, offset, EXEC dance, nop, load; prologue / chain transition / alignment
+          const size_t b_unit = 256 + nrows[blk] * 24 + recs[blk] * 40 + pieces_per_unit * 56;
+          bound = std::max(bound, b_unit);
+        }
+      }
+  }
   int n_pref = 1;
-  while ((size_t)n_pref * 4096 < max_unit + 16 + (size_t)n_pref * 20) ++n_pref;
-  max_unit = 0;
-  return build_pass(g, t, rowptr, colidx, values, opt, n_pref, &max_unit, chan);
+  while ((size_t)n_pref * 4096 < bound + (size_t)n_pref * 20) ++n_pref;
+  Program p = build_pass(g, t, rowptr, colidx, values, opt, n_pref, &max_unit, chan);
+  if (!p.overflow && max_unit > (size_t)n_pref * 4096) {
+    // (the bound was not one: generate again with what the longest unit really needs)
+    while ((size_t)n_pref * 4096 < max_unit + 16 + (size_t)n_pref * 20) ++n_pref;
+    max_unit = 0;
+    p = build_pass(g, t, rowptr, colidx, values, opt, n_pref, &max_unit, chan);
+  }
+  return p;
 }
 
 }  // namespace jit

@@ -2,7 +2,9 @@
 #include "stream_builder.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 
@@ -275,6 +277,8 @@ std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const
       ++recs[(size_t)m * nb + b];
     }
   auto count_of = [&](int o) { return std::max(0, std::min(G, Mg - o * G)); };
+  // (one workgroup column at a time; the columns touch disjoint slots and run on threads of their own below)
+  auto deal_column = [&](int blk0) {
   std::vector<uint64_t> acc(words);
   auto wave_cost = [&](int o, int b) {      // cost of oc-group o in block b under `slot`
     std::fill(acc.begin(), acc.end(), 0ull);
@@ -290,9 +294,9 @@ std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const
     for (int w = 0; w < words; ++w) rows += __builtin_popcountll(acc[w]);
     return kGroupCost * rows + kRecordCost * rc;
   };
-  for (int blk0 = 0; blk0 < n_ocg; blk0 += t.oc_waves) {          // one workgroup column
+  {
     const int nw = std::min(t.oc_waves, n_ocg - blk0);
-    if (nw < 2) continue;
+    if (nw < 2) return;
     std::vector<double> cost((size_t)nw * nb);
     for (int w = 0; w < nw; ++w)
       for (int b = 0; b < nb; ++b) cost[(size_t)w * nb + b] = wave_cost(blk0 + w, b);
@@ -337,6 +341,26 @@ std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const
             }
       if (!improved) break;
     }
+  }
+  };
+  // WeightAlign is host time the caller waits for (res5: 70 ms of channel deal in one thread): the columns are
+  // independent, so large layers deal them on up to eight threads.  Deterministic: a column's result does not
+  // depend on the others'.
+  std::vector<int> cols;
+  for (int blk0 = 0; blk0 < n_ocg; blk0 += t.oc_waves) cols.push_back(blk0);
+  const size_t work = (size_t)Mg * nb * words;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t n_thr = work >= 4096 && cols.size() > 1 ? std::min<size_t>(std::min<size_t>(8, hw), cols.size()) : 1;
+  if (n_thr <= 1) {
+    for (int blk0 : cols) deal_column(blk0);
+  } else {
+    std::vector<std::thread> pool;
+    std::atomic<size_t> next{0};
+    for (size_t th = 0; th < n_thr; ++th)
+      pool.emplace_back([&]() {
+        for (size_t i = next.fetch_add(1); i < cols.size(); i = next.fetch_add(1)) deal_column(cols[i]);
+      });
+    for (auto &th : pool) th.join();
   }
   // slots past the last channel of a partly filled oc-group repeat a valid channel
   return slot;
