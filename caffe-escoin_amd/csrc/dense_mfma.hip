@@ -533,9 +533,10 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   const long nk = (g.kdim + kBK - 1) / kBK;
   const long rounds = (tiles + slots - 1) / slots;
   const double occupancy = (double)tiles / (double)(rounds * slots);
-  // (pointwise layers only: with the 4-byte gathers of the other operand path the stride-2 1x1 layer res5a_branch1
-  //  went from 581 to 629 us)
-  bool streamk = sk_env >= 0 ? sk_env != 0 : (vec_b && occupancy < 0.85 && nk >= 8 && tiles * nk >= 4 * slots);
+  // (1x1 layers of stride 1 only: that is what was measured -- the stride-2 layer res5a_branch1 went from 581 to 629 us
+  //  with it, 3x3 layers have not been tried)
+  const bool unit_1x1 = g.d.KH == 1 && g.d.KW == 1 && g.d.stride_h == 1 && g.d.stride_w == 1;
+  bool streamk = sk_env >= 0 ? sk_env != 0 : (unit_1x1 && occupancy < 0.85 && nk >= 8 && tiles * nk >= 4 * slots);
   if (tiles * nk < slots) streamk = false;
   const long n_wg = streamk ? slots : std::min<long>(tiles, slots);
   a.sk_ws = nullptr;

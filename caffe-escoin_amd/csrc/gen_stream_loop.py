@@ -660,6 +660,43 @@ def main():
                     ]
             lines.append("ESC_QX%d_%d_%%=:" % (tile, r))
             emit_macro(out, "ESC_EPI1SP_%d_%d" % (tile, r), lines)
+    # ESC_EPI1SS_<tile>: strided pointwise layers (1x1, stride 2): a lane's quad holds four INPUT columns, elements
+    # 0 and 2 of it are two adjacent outputs -- packed into one register pair and stored as a dwordx2 under %[ok];
+    # a row's last quad may hold one output only (input width 14: columns 12, 13 and two of the next row): a dword
+    # under %[okp]
+    for tile, base in ((0, ACC_A), (1, ACC_B)):
+        lines = ["s_mov_b64 s[32:33], exec", "s_mov_b64 s[34:35], %[base]"]
+        ng = NACC_TILE // 4
+        for g in range(ng):
+            C0 = base + 4 * g
+            lines += [
+                "v_mov_b32 v%d, v%d" % (C0 + 1, C0 + 2),
+                "s_bitcmp1_b32 %[flags], 0",
+                "s_cbranch_scc0 ESC_SB%d_%d_%%=" % (tile, g),
+                "v_readlane_b32 s36, %%[bias], %d" % g,
+                "s_nop 1",
+                "v_pk_add_f32 v[%d:%d], v[%d:%d], s[36:37] op_sel_hi:[1,0]" % (C0, C0 + 1, C0, C0 + 1),
+                "ESC_SB%d_%d_%%=:" % (tile, g),
+                "s_bitcmp1_b32 %[flags], 1",
+                "s_cbranch_scc0 ESC_SR%d_%d_%%=" % (tile, g),
+                "v_max_f32 v%d, 0, v%d" % (C0, C0),
+                "v_max_f32 v%d, 0, v%d" % (C0 + 1, C0 + 1),
+                "ESC_SR%d_%d_%%=:" % (tile, g),
+                "s_mov_b64 exec, %[ok]",
+                "global_store_dwordx2 %%[voff], v[%d:%d], s[34:35]%s" % (C0, C0 + 1, STORE_MOD),
+                "s_mov_b64 exec, %[okp]",
+                "global_store_dword %%[voff], v%d, s[34:35]%s" % (C0, STORE_MOD),
+                "s_mov_b64 exec, s[32:33]",
+            ]
+            if g + 1 < ng:
+                lines += [
+                    "s_add_u32 s34, s34, %[ostr]",
+                    "s_addc_u32 s35, s35, 0",
+                    "s_cmp_eq_u32 %%[gcount], %d" % (g + 1),
+                    "s_cbranch_scc1 ESC_SX%d_%%=" % tile,
+                ]
+        lines.append("ESC_SX%d_%%=:" % tile)
+        emit_macro(out, "ESC_EPI1SS_%d" % tile, lines)
     out.write("#define ESC_EPI3S_CLOBBERS \"memory\", \"scc\", \"s32\", \"s33\", \"s34\", \"s35\", \"s36\", \"s37\", \"s38\", \"s39\", ")
     out.write(", ".join('\"v%d\"' % i for i in range(ACC_A, 256)))
     out.write("\n")

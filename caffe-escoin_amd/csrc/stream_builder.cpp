@@ -83,7 +83,7 @@ Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int 
   // A pointwise image walked as ONE row by a workgroup of its own (14 x 14 as 1 x 196: 49 quads on a
   // 64-quad row) needs no row pitch: the planes are packed to the quads that exist.  Lanes past the row
   // read the next channel's quads (theirs are results nobody stores); the fill moves 23 % fewer bytes.
-  if (g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && !t.band_mode && t.nseg == 1 && t.tr == 1 &&
+  if (g.sub == 1 && g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && !t.band_mode && t.nseg == 1 && t.tr == 1 &&
       !(getenv("ESCOIN_PACK_ROW") && atoi(getenv("ESCOIN_PACK_ROW")) == 0))
     t.plane_ch_floats = std::min(t.plane_ch_floats, (g.W + 7) / 8 * 8);   // (whole 32 bytes: the stream's row offsets)
   const int per_ch = t.plane_ch_floats * 4;
@@ -190,7 +190,7 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, 
   // (then: fewest copies that straddle, best lane use, longest rows).  56 x 56 is walked as 49 x 64,
   // 28 x 28 as 98 x 8, 14 x 14 as 7 x 28: no or 1/8 padding instead of 1/8 .. 1/4.  Input and output
   // blobs are the same memory either way.
-  if (g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H && g.OW == g.W) {
+  if (g.sub == 1 && g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && g.OH == g.H && g.OW == g.W) {
     const int hw = g.H * g.W;
     auto slots = [](const Tiling &t) {   // 16-byte LDS slots staged per image and channel
       return t.band_mode ? (long)t.bands * t.plane_rows * t.S4 : (long)t.plane_ch_floats / 4 / t.nseg;

@@ -33,6 +33,10 @@ struct ConvGeom {
   int N, C, H, W, M, KH, KW, pad_h, pad_w, group;
   int OH, OW, Cg, Mg;
   float density = 0.f;   // nonzero fraction of the weights (0: unknown); steers the tiling choice
+  int sub = 1;           // strided pointwise layers (1x1, stride `sub`, no padding): H x W here is the VIEW the kernel
+                         // walks -- OH rows (input rows 0, sub, 2 sub, ...) of the full input width; lanes own input quads
+                         // and every sub-th element of a quad is an output.  The rows of such a view are not contiguous
+                         // in memory: no re-cut, no row packing.
 };
 
 struct Tiling {

@@ -893,8 +893,14 @@ def test_kernel_auto_follows_the_measured_crossover(pkg, synth, torch_cuda):
     assert choice(rn[2], 0.3) == pkg.KERNEL_JIT          # res4: 605 against 692
     assert choice(al[1], 0.4) == pkg.KERNEL_DENSE        # AlexNet conv3: 409 against 380
     assert choice(gl[5], 0.3) == pkg.KERNEL_DENSE        # inception_3b 256@28x28 -> 128: 174 against 143
-    # stride 2 (ResNet-50's res3a_branch2a, pruned): no tiled kernel -- dense above 4 % density, generic below
+    # stride 2, 1x1 (ResNet-50's res3a_branch2a, pruned): the pointwise path over a strided view of the bottom blob
     s2 = synth.shape("res3a_branch2a", 2, 256, 56, 56, 128, 1, stride=2, bias=False, sparsity=0.9)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s2), tiling_batch=256)
+    plan.weight_align(synth.pruned_weights(s2, 3))
+    assert plan.stat("kernel_choice") == pkg.KERNEL_JIT, plan.kernel_name
+    plan.close()
+    # a geometry no tiled kernel covers (3x3, stride 2): dense above 4 % density, the generic kernel below
+    s2 = synth.shape("k3s2", 2, 64, 28, 28, 64, 3, stride=2, pad=1, bias=False, sparsity=0.9)
     plan = pkg.Plan(pkg.ConvDesc.from_shape(s2), tiling_batch=256)
     plan.weight_align(synth.pruned_weights(s2, 3))
     assert plan.stat("kernel_choice") == pkg.KERNEL_DENSE, plan.kernel_name
@@ -903,4 +909,47 @@ def test_kernel_auto_follows_the_measured_crossover(pkg, synth, torch_cuda):
     plan = pkg.Plan(pkg.ConvDesc.from_shape(s3), tiling_batch=256)
     plan.weight_align(synth.pruned_weights(s3, 3))
     assert plan.stat("kernel_choice") == pkg.KERNEL_GENERIC, plan.kernel_name
+    plan.close()
+
+
+def test_strided_pointwise_layers(pkg, oracle, synth, torch_cuda):
+    """1x1 convolutions with stride 2 (ResNet-50's res{3,4,5}a_branch1 / branch2a) on the tiled path: even input rows
+    staged whole, elements 0 and 2 of a lane's quad stored.  Generated code and the stream kernel against the oracle
+    at small batch through the tiling of batch 256; odd heights, bias + ReLU, few channels (waves without an
+    oc-group: unchained units), conv groups; widths that are not whole quads fall back (dense / generic kernel)."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    cases = [synth.shape("res3a_branch2a", 5, 256, 56, 56, 128, 1, stride=2, bias=False, sparsity=0.9),
+             synth.shape("res4a_branch1", 5, 512, 28, 28, 1024, 1, stride=2, bias=False, sparsity=0.9),
+             synth.shape("res5a_branch2a", 7, 1024, 14, 14, 512, 1, stride=2, bias=True, sparsity=0.9),
+             synth.shape("odd_h", 3, 24, 13, 20, 40, 1, stride=2, bias=True, sparsity=0.8),
+             synth.shape("w54", 3, 24, 9, 54, 40, 1, stride=2, bias=True, sparsity=0.8),
+             synth.shape("few_ch", 3, 16, 12, 12, 5, 1, stride=2, bias=True, sparsity=0.5),
+             synth.shape("groups", 3, 32, 8, 16, 48, 1, stride=2, group=2, bias=True, sparsity=0.85)]
+    for k, s in enumerate(cases):
+        w, b = synth.pruned_weights(s, 500 + k), synth.bias_vector(s, 520 + k)
+        x = synth.activations(s, 540 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, 1, 1, 0, 0, 2, 2, 1, 1, s.group)
+        for relu in (False, True):
+            want = oracle.conv_forward(g, x, w, b, relu=relu, gate=False, threads=4)
+            for kernel in (pkg.KERNEL_AUTO, pkg.KERNEL_JIT, pkg.KERNEL_TILED):
+                for tb in (0, 256):
+                    plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), kernel=kernel, tiling_batch=tb)
+                    plan.weight_align(w)
+                    assert _fast(plan.kernel_name), (s.name, plan.kernel_name)
+                    top = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev) if b is not None else None)
+                    torch.cuda.synchronize()
+                    err = rel_err(top.cpu().numpy(), want)
+                    assert err <= TOL, "%s via %s (tiling_batch %d, relu %d): %g" % (s.name, plan.kernel_name, tb, relu, err)
+                    plan.close()
+    # an odd input width: no strided view (rows would not start on 16-byte boundaries) -- the layer still computes
+    # (dense MFMA / generic kernel)
+    s = synth.shape("w55", 2, 16, 10, 55, 8, 1, stride=2, bias=True, sparsity=0.5)
+    w, b, x = synth.pruned_weights(s, 7), synth.bias_vector(s, 8), synth.activations(s, 9)
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    plan.weight_align(w)
+    assert not _fast(plan.kernel_name), plan.kernel_name
+    g = oracle.geom(s.C, s.H, s.W, s.M, 1, 1, 0, 0, 2, 2, 1, 1, 1)
+    top = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev))
+    assert rel_err(top.cpu().numpy(), oracle.conv_forward(g, x, w, b, gate=False)) <= TOL
     plan.close()
