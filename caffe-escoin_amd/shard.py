@@ -58,3 +58,20 @@ def broadcast_csr(csr, n_groups, n_rowptr, nnz, src=0, device="cpu", group=None)
         t = torch.empty(n, dtype=torch.int32, device=device)
     dist.broadcast(t, src=src, group=group)
     return unpack_csr(t.cpu().numpy())
+
+
+def broadcast_blob(blob, src=0, device="cpu", group=None):
+    """Broadcast a byte blob (numpy uint8 on the source rank, ignored elsewhere) whose size only the source
+    knows: the aligned form of a layer (escoin_plan_export_aligned: CSR + channel deal + unit table + code
+    object), so that receivers load the code rank 0 generated instead of generating their own."""
+    import torch
+    import torch.distributed as dist
+    is_src = dist.get_rank(group) == src
+    n = torch.tensor([int(blob.size) if is_src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src, group=group)
+    if is_src:
+        t = torch.from_numpy(np.ascontiguousarray(blob, np.uint8)).to(device)
+    else:
+        t = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src, group=group)
+    return t.cpu().numpy()

@@ -52,7 +52,11 @@ def _worker(rank, world, port, out_dir):
     x = synth.activations(s, 9, b, e - b)          # seeded by GLOBAL image index
     geom = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, group=s.group)
     top = oracle.conv_forward(geom, x, w_rx.reshape(s.M, cg, s.KH, s.KW), None, gate=False)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), top=top, b=b, e=e, w=w_rx)
+    # the byte-blob broadcast bench.py uses for the aligned form (size known to the source only)
+    blob = np.arange(100003, dtype=np.uint64).view(np.uint8)[5:] if rank == 0 else None
+    got = pkg.shard.broadcast_blob(blob, src=0)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), top=top, b=b, e=e, w=w_rx, blob_sum=int(got.astype(np.uint64).sum()),
+             blob_len=got.size)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,6 +74,9 @@ def test_two_rank_shard_and_broadcast(tmp_path, pkg, oracle, synth):
     for p in parts:
         assert np.array_equal(p["w"].reshape(w.shape), w)      # broadcast delivered the weights
     assert np.array_equal(np.concatenate([p["top"] for p in parts]), full)
+    want = np.arange(100003, dtype=np.uint64).view(np.uint8)[5:]
+    for p in parts:
+        assert int(p["blob_len"]) == want.size and int(p["blob_sum"]) == int(want.astype(np.uint64).sum())
 
 
 def test_shard_range_covers_batch(pkg):
