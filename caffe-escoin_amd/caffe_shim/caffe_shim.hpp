@@ -332,6 +332,29 @@ class BaseConvolutionLayer : public Layer<Dtype> {   // base_conv_layer.hpp:20-2
     aligned_ = true;
   }
 
+  // The aligned form as one byte blob (CSR + channel deal + unit table + code object), and WeightAlign from such
+  // a blob instead of from blobs_[0]: what a Net::CopyTrainedLayersFrom that finds "<model>.escoin/<layer>.bin"
+  // next to the .caffemodel would call (the reference recomputes the aligned form at every load, net.cpp:819; here
+  // it contains compiled code, so a deployment persists it once).  Returns true when the persisted code object was
+  // loaded as it was; a blob written for other options / batch / device falls back to aligning from its CSR.
+  vector<unsigned char> ExportAligned() const {
+    ESC_CHECK(plan_ != nullptr && aligned_);
+    size_t n = 0;
+    ESCOIN_CHECK(escoin_plan_export_aligned(plan_, nullptr, 0, &n));
+    vector<unsigned char> blob(n);
+    ESCOIN_CHECK(escoin_plan_export_aligned(plan_, blob.data(), blob.size(), &n));
+    blob.resize(n);
+    return blob;
+  }
+  bool WeightAlignFrom(const vector<unsigned char> &blob) {
+    ESC_CHECK(plan_ != nullptr);
+    ESCOIN_CHECK(escoin_plan_set_option(plan_, "conv_mode", (int)Caffe::conv_mode()));
+    aligned_mode_ = Caffe::conv_mode();
+    ESCOIN_CHECK(escoin_plan_import_aligned(plan_, blob.data(), blob.size(), Caffe::stream()));
+    aligned_ = true;
+    return escoin_plan_stat(plan_, "import_fast") == 1;
+  }
+
   virtual inline int MinBottomBlobs() const { return 1; }
   virtual inline int MinTopBlobs() const { return 1; }
   virtual inline bool EqualNumBottomTopBlobs() const { return true; }

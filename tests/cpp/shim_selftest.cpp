@@ -5,6 +5,7 @@
 // Needs a GPU; run by tests/test_shim_gpu.py.  Prints one line per case, exit code = #failures.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "caffe_shim.hpp"
@@ -145,6 +146,37 @@ static int reshape_case() {
   return bad;
 }
 
+// A layer restored from the aligned form another layer exported (no dense blob, no WeightAlign): same numbers,
+// bit for bit, and the persisted code object loaded as it was.
+static int aligned_form_case() {
+  LayerParameter lp;
+  lp.name = "aligned";
+  lp.type = "Convolution";
+  lp.convolution_param.num_output = 64; lp.convolution_param.kernel_h = lp.convolution_param.kernel_w = 3;
+  lp.convolution_param.pad_h = lp.convolution_param.pad_w = 1;
+  lp.convolution_param.bias_term = false;
+  Blob<float> b0(4, 32, 14, 14), t0, t1;
+  std::vector<Blob<float> *> bottom(1, &b0), top0(1, &t0), top1(1, &t1);
+  float *x = b0.mutable_cpu_data();
+  for (int k = 0; k < b0.count(); ++k) x[k] = frand();
+  ConvolutionLayer<float> a(lp), b(lp);
+  a.SetUp(bottom, top0);
+  b.SetUp(bottom, top1);
+  float *w = a.blobs()[0]->mutable_cpu_data();
+  for (int k = 0; k < a.blobs()[0]->count(); ++k) { const float v = frand(); w[k] = (std::fabs(frand()) < 0.9f) ? 0.f : (v == 0.f ? 0.25f : v); }
+  a.WeightAlign();
+  a.Forward(bottom, top0);
+  const std::vector<unsigned char> blob = a.ExportAligned();
+  const bool fast = b.WeightAlignFrom(blob);        // b's blobs_[0] was never filled
+  b.Forward(bottom, top1);
+  const bool same = memcmp(t0.cpu_data(), t1.cpu_data(), sizeof(float) * t0.count()) == 0;
+  const bool code = strstr(a.kernel_name(), "jit") != nullptr;
+  const bool ok = same && b.nnz() == a.nnz() && (fast || !code);
+  printf("%-22s %-28s blob %zu bytes, code object loaded as persisted: %s, outputs identical: %s %s\n", "aligned_form", a.kernel_name(),
+         blob.size(), fast ? "yes" : "no", same ? "yes" : "no", ok ? "OK" : "FAIL");
+  return ok ? 0 : 1;
+}
+
 static ConvolutionParameter P(int m, int k, int pad = 0, int stride = 1, int group = 1, bool bias = true,
                               int dil = 1) {
   ConvolutionParameter cp;
@@ -173,6 +205,7 @@ int main() {
   bad += run_case<ConvolutionReLULayer<float> >("conv_relu_k3p1", 2, 16, 13, 13, P(24, 3, 1), 0.8f, true);
   Caffe::set_conv_mode(Caffe::SCONV_PAR);
   bad += reshape_case();
+  bad += aligned_form_case();
   printf(bad ? "shim self-test: %d FAILED\n" : "shim self-test: all OK\n", bad);
   return bad;
 }
