@@ -69,6 +69,7 @@ struct Lds {
   int issue() { return issued++; }
   void wait_for(int id) {       // operation `id` (0-based issue order) must have landed
     if (id < done) return;
+    if (ablate & 64) { done = id + 1; return; }      // (timing only: nobody waits for LDS)
     enc_waitcnt_lgkm(c, std::min(15, issued - 1 - id));
     done = std::max(done, issued - std::min(15, issued - 1 - id));
   }
@@ -178,6 +179,13 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
   first_of_row[n] = (int)flat.size();
   auto sreg = [](int j) { return (j & 1) ? kSWeight1 : kSWeight0; };
   if (opt.hoist_weight && !flat.empty() && !(opt.ablate & 4)) enc_s_mov_lit(c, sreg(0), flat[0]->bits);
+  if ((opt.ablate & 4) && (opt.ablate & 16384)) {
+    // no weight moves, but two nonzero weights in the registers: the FMAs do real arithmetic.  (With whatever the
+    // registers held -- zeros -- the chip draws less power and clocks higher: bit 2 alone overstates the moves' cost
+    // by a factor of three, profiles/r04_walk_limits.md)
+    enc_s_mov_lit(c, kSWeight0, 0x3F9E3779u);
+    enc_s_mov_lit(c, kSWeight1, 0xBF4A7B2Du);
+  }
   int prio = 0;
   for (int k = 0; k < n; ++k) {
     read_tables(k);
@@ -199,11 +207,16 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
       }
       if (opt.ablate & 1) continue;
       const int a = 4 * flat[j]->idx;
-      enc_pk_fma(c, kAccA + a, sreg(j), xa);
-      enc_pk_fma(c, kAccA + a + 2, sreg(j), xa + 2);
+      // (timing only: 512 = an s_nop behind every FMA -- four more instructions and 16 more bytes per nonzero)
+      auto fma = [&](int acc, int x) {
+        enc_pk_fma(c, acc, sreg(j), x);
+        if (opt.ablate & 512) enc_nop(c);
+      };
+      fma(kAccA + a, xa);
+      fma(kAccA + a + 2, xa + 2);
       if (opt.one_tile) continue;
-      enc_pk_fma(c, kAccB + a, sreg(j), xb);
-      enc_pk_fma(c, kAccB + a + 2, sreg(j), xb + 2);
+      fma(kAccB + a, xb);
+      fma(kAccB + a + 2, xb + 2);
     }
   }
   // whatever the rows did not take (short or empty units): two at a time
@@ -217,8 +230,8 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     // walked must have landed: with one fill in flight that is all of it; with two, all but this unit's own
     // vector-memory operations (its code touches and its pieces, which stage the block after the next).
     const int younger = opt.dma.ahead >= 2 ? n_pref + (int)pieces.size() : 0;
-    enc_waitcnt_vm(c, std::min(63, younger));
-    enc_barrier(c);
+    if (!(opt.ablate & 32)) enc_waitcnt_vm(c, std::min(63, younger));
+    if (!(opt.ablate & 16)) enc_barrier(c);
     const uint32_t all = (uint32_t)opt.chain.nbuf * opt.chain.buf_bytes;
     enc_s_mov(c, kSChainTmp, kSWalkBase);
     enc_s_add_u32_lit(c, kSWalkBase, kSWalkBase, opt.chain.buf_bytes);

@@ -203,7 +203,10 @@ struct Options {
                           // first-dispatched half loses to a second half that runs at a constant priority 1
                           // and wins every tie against it at 1 (oldest first), so it alternates
   int ablate = 0;         // timing experiments only (ESCOIN_JIT_ABL; wrong results): 1 no FMAs, 2 no LDS
-                          // reads, 4 no weight moves, 8 empty units
+                          // reads, 4 no weight moves (+ 16384: with two nonzero weights in the registers), 8 empty
+                          // units, 16 no barrier between chained units, 32 no wait for the plane DMA there, 64 no
+                          // waits for LDS reads, 512 an s_nop behind every FMA.  Builds that change the DATA the FMAs
+                          // see (1, 2, 4 alone) also change the chip's clock: profiles/r04_walk_limits.md
   DmaPlan dma;
   ChainPlan chain;
   int prefetch = 1;       // touch the next unit's code (above)
