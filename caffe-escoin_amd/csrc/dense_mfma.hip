@@ -172,8 +172,9 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         const int i = wave + 4 * q;          // rows k0 + 2 i, k0 + 2 i + 1
         // rows past K (the last k-step when Cg % 32 != 0) are channels of the next conv group, of the
         // next image or memory past the blob: A's zero padding does not make them harmless (0 * Inf,
-        // 0 * NaN = NaN), so they are staged as zeros like the gathered path's 0x7FFF taps -- the
-        // range check sees the VGPR offset only, hence the marker goes there
+        // 0 * NaN = NaN), so they are staged as zeros like the gathered path's 0x7FFF taps: the marker in
+        // the VGPR offset puts the address out of range whatever the scalar offset (the descriptor's range
+        // check is on the sum of the two: tools/probes/probe_rsrc_range.hip, profiles/r04_probe_rsrc_range.txt)
         const unsigned vo = (k0 + 2 * i + (lane >> 5) < a.K) ? fb_pix[0] : kOOB;
         dma16(rB, ldsB + (unsigned)buf * kBufBytes + (unsigned)(i * 1024), vo, (unsigned)((size_t)(k0 + 2 * i) * hw * 4));
       }
