@@ -2,11 +2,13 @@
 #include "jit_module.h"
 
 #include <amd_comgr/amd_comgr.h>
+#include <elf.h>
 #include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "escoin_plan.h"
@@ -190,7 +192,7 @@ int jit_load_elf(const std::vector<char> &elf, size_t code_bytes, JitModule *out
   return ESCOIN_OK;
 }
 
-int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream, std::vector<char> *keep_elf) {
+int jit_assemble(const std::vector<uint32_t> &code, std::vector<char> *elf) {
   if (code.empty()) return fail(ESCOIN_EINVAL, "jit: empty program");
   // the bytes reach the assembler through .incbin: a file, gone again before this returns
   std::string path = tmp_dir() + "/escoin_jit_XXXXXX";
@@ -208,11 +210,119 @@ int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stre
   close(fd);
   std::string src = kWrapper;
   src.replace(src.find("%BLOB%"), 6, pbuf.data());
-  std::vector<char> elf;
-  const std::string err = done == bytes ? assemble_and_link(src, &elf) : std::string("short write to the temporary file");
+  elf->clear();
+  const std::string err = done == bytes ? assemble_and_link(src, elf) : std::string("short write to the temporary file");
   unlink(pbuf.data());
   if (!err.empty()) return fail(ESCOIN_EHIP, "jit: " + err);
-  const int rc = jit_load_elf(elf, bytes, out, stream);
+  return ESCOIN_OK;
+}
+
+namespace {
+constexpr size_t kTemplateCode = 4096;     // bytes of s_nop the template carries where the code goes
+struct WrapTemplate {
+  std::vector<char> elf;
+  size_t code_off = 0;                     // file offset of the first code byte
+  uint64_t code_addr = 0;                  // ... and its address
+  bool ok = false;
+};
+// The template, parsed once: where escoin_jit_code lies in the file.
+const WrapTemplate &wrap_template() {
+  static WrapTemplate t;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    const std::vector<uint32_t> nops(kTemplateCode / 4, 0xBF800000u);
+    if (jit_assemble(nops, &t.elf) != ESCOIN_OK || t.elf.size() < sizeof(Elf64_Ehdr)) return;
+    const Elf64_Ehdr *eh = reinterpret_cast<const Elf64_Ehdr *>(t.elf.data());
+    if (std::memcmp(eh->e_ident, ELFMAG, SELFMAG) != 0 || eh->e_ident[EI_CLASS] != ELFCLASS64 || eh->e_shentsize != sizeof(Elf64_Shdr) ||
+        eh->e_phentsize != sizeof(Elf64_Phdr) || eh->e_shoff + (size_t)eh->e_shnum * sizeof(Elf64_Shdr) > t.elf.size())
+      return;
+    const Elf64_Shdr *sh = reinterpret_cast<const Elf64_Shdr *>(t.elf.data() + eh->e_shoff);
+    for (int i = 0; i < eh->e_shnum; ++i) {
+      if (sh[i].sh_type != SHT_SYMTAB) continue;
+      const Elf64_Shdr &str = sh[sh[i].sh_link];
+      const Elf64_Sym *sym = reinterpret_cast<const Elf64_Sym *>(t.elf.data() + sh[i].sh_offset);
+      for (size_t k = 0; k < sh[i].sh_size / sizeof(Elf64_Sym); ++k) {
+        if (std::strcmp(t.elf.data() + str.sh_offset + sym[k].st_name, "escoin_jit_code") != 0) continue;
+        const Elf64_Shdr &text = sh[sym[k].st_shndx];
+        t.code_addr = sym[k].st_value;
+        t.code_off = (size_t)(text.sh_offset + (sym[k].st_value - text.sh_addr));
+        // the placeholder must be where the symbol says, whole, inside the section
+        bool nop = t.code_off + kTemplateCode <= text.sh_offset + text.sh_size;
+        for (size_t b = 0; nop && b < kTemplateCode; b += 4)
+          nop = *reinterpret_cast<const uint32_t *>(t.elf.data() + t.code_off + b) == 0xBF800000u;
+        t.ok = nop;
+      }
+    }
+  });
+  return t;
+}
+}  // namespace
+
+int jit_wrap(const std::vector<uint32_t> &code, std::vector<char> *elf) {
+  if (code.empty()) return fail(ESCOIN_EINVAL, "jit: empty program");
+  const WrapTemplate &t = wrap_template();
+  if (!t.ok) return fail(ESCOIN_EHIP, "jit: no code object template");
+  const size_t bytes = code.size() * 4, padded = (bytes + 4095) / 4096 * 4096;
+  const uint64_t delta = padded - kTemplateCode;
+  const size_t cut = t.code_off + kTemplateCode;            // file offset everything from which moves
+  const uint64_t cut_addr = t.code_addr + kTemplateCode;
+  elf->resize(t.elf.size() + delta);
+  char *o = elf->data();
+  std::memcpy(o, t.elf.data(), t.code_off);
+  std::memcpy(o + t.code_off, code.data(), bytes);
+  for (size_t b = bytes; b < padded; b += 4) { const uint32_t nop = 0xBF800000u; std::memcpy(o + t.code_off + b, &nop, 4); }
+  std::memcpy(o + t.code_off + padded, t.elf.data() + cut, t.elf.size() - cut);
+  if (delta == 0) return ESCOIN_OK;
+  Elf64_Ehdr *eh = reinterpret_cast<Elf64_Ehdr *>(o);
+  if (eh->e_shoff >= cut) eh->e_shoff += delta;
+  if (eh->e_phoff >= cut) eh->e_phoff += delta;
+  Elf64_Phdr *ph = reinterpret_cast<Elf64_Phdr *>(o + eh->e_phoff);
+  for (int i = 0; i < eh->e_phnum; ++i) {
+    if (ph[i].p_offset >= cut) {
+      ph[i].p_offset += delta; ph[i].p_vaddr += delta; ph[i].p_paddr += delta;
+    } else if (ph[i].p_offset + ph[i].p_filesz >= cut) {     // the segment that holds the code
+      ph[i].p_filesz += delta; ph[i].p_memsz += delta;
+    }
+  }
+  Elf64_Shdr *sh = reinterpret_cast<Elf64_Shdr *>(o + eh->e_shoff);
+  for (int i = 0; i < eh->e_shnum; ++i) {
+    if (sh[i].sh_type == SHT_NULL) continue;
+    if (sh[i].sh_offset >= cut) {
+      sh[i].sh_offset += delta;
+      if (sh[i].sh_addr >= cut_addr) sh[i].sh_addr += delta;
+    } else if (sh[i].sh_offset + sh[i].sh_size >= cut && sh[i].sh_type != SHT_NOBITS) {
+      sh[i].sh_size += delta;                                // .text
+    }
+  }
+  for (int i = 0; i < eh->e_shnum; ++i) {
+    if (sh[i].sh_type == SHT_SYMTAB || sh[i].sh_type == SHT_DYNSYM) {
+      Elf64_Sym *sym = reinterpret_cast<Elf64_Sym *>(o + sh[i].sh_offset);
+      for (size_t k = 0; k < sh[i].sh_size / sizeof(Elf64_Sym); ++k)
+        if (sym[k].st_shndx != SHN_UNDEF && sym[k].st_shndx < SHN_LORESERVE && sym[k].st_value >= cut_addr) sym[k].st_value += delta;
+    } else if (sh[i].sh_type == SHT_DYNAMIC) {
+      Elf64_Dyn *dyn = reinterpret_cast<Elf64_Dyn *>(o + sh[i].sh_offset);
+      for (size_t k = 0; k < sh[i].sh_size / sizeof(Elf64_Dyn) && dyn[k].d_tag != DT_NULL; ++k)
+        switch (dyn[k].d_tag) {
+          case DT_HASH: case DT_GNU_HASH: case DT_STRTAB: case DT_SYMTAB: case DT_RELA: case DT_REL: case DT_JMPREL: case DT_PLTGOT:
+          case DT_INIT: case DT_FINI: case DT_INIT_ARRAY: case DT_FINI_ARRAY:
+            if (dyn[k].d_un.d_ptr >= cut_addr) dyn[k].d_un.d_ptr += delta;
+            break;
+          default: break;
+        }
+    }
+  }
+  return ESCOIN_OK;
+}
+
+int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream, std::vector<char> *keep_elf) {
+  static const bool wrap = !(getenv("ESCOIN_JIT_WRAP") && atoi(getenv("ESCOIN_JIT_WRAP")) == 0);
+  std::vector<char> elf;
+  int rc = wrap ? jit_wrap(code, &elf) : ESCOIN_EHIP;
+  if (rc == ESCOIN_OK) rc = jit_load_elf(elf, code.size() * 4, out, stream);
+  if (rc != ESCOIN_OK) {       // (no template, or a loader that does not take the grown one: the assembler's own)
+    rc = jit_assemble(code, &elf);
+    if (rc == ESCOIN_OK) rc = jit_load_elf(elf, code.size() * 4, out, stream);
+  }
   if (rc == ESCOIN_OK && keep_elf) keep_elf->swap(elf);
   return rc;
 }

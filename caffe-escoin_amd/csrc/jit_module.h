@@ -27,6 +27,16 @@ bool jit_available();
 // current device and asks the locator where the code landed.  ESCOIN_* status.
 // keep_elf != nullptr: the code object's bytes are handed back (escoin_plan_export_aligned persists them).
 int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream, std::vector<char> *keep_elf = nullptr);
+// The two ways to the code object's bytes (no device involved; both testable on a CPU-only box):
+//   jit_assemble  the assembler and linker run on the wrapper around `code` (19 ms per megabyte of code);
+//   jit_wrap      the SAME bytes without them: a template -- the wrapper around 4 KiB of s_nop, assembled once per
+//                 process -- whose .text is grown by the code (padded to whole pages with s_nop): everything behind
+//                 the insertion point moves by a whole number of pages, so file offsets, addresses and segment
+//                 alignments move together, and the headers, section table and symbols are rewritten accordingly.
+//                 tests/test_jit_codegen.py holds the two byte-identical.
+// jit_load uses jit_wrap and falls back to jit_assemble (ESCOIN_JIT_WRAP=0: always the assembler).
+int jit_assemble(const std::vector<uint32_t> &code, std::vector<char> *elf);
+int jit_wrap(const std::vector<uint32_t> &code, std::vector<char> *elf);
 // Loads a code object jit_load produced earlier (same library build, same target): no assembler run.
 int jit_load_elf(const std::vector<char> &elf, size_t code_bytes, JitModule *out, hipStream_t stream);
 void jit_unload(JitModule *m);

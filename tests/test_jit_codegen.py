@@ -31,3 +31,23 @@ def test_encoders_agree_with_the_assembler(tmp_path):
         b = bytes(int(x, 16) for x in enc.split(","))
         theirs = [int.from_bytes(b[i:i + 4], "little") for i in range(0, len(b), 4)]
         assert words == theirs, "%s: %s vs llvm-mc %s" % (text, [hex(w) for w in words], [hex(w) for w in theirs])
+
+
+def test_code_object_without_the_assembler_is_the_assemblers(tmp_path):
+    """jit_module.h jit_wrap: the template's .text grown by the generated code, headers / section table / symbols
+    rewritten, against jit_assemble (libamd_comgr: assembler + linker) on the same page-padded code -- byte for byte."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.build()      # (the library's objects: the check links jit_module.o and what it refers to)
+    objs = [os.path.join(CSRC, o) for o in ("jit_module.o", "escoin_capi.o", "sconv_generic.o", "sconv_tiled.o", "dense_mfma.o",
+                                            "sconv_lowered.o", "stream_builder.o", "jit_codegen.o")]
+    assert all(os.path.exists(o) for o in objs)
+    obj, exe = str(tmp_path / "jit_wrap_check.o"), str(tmp_path / "jit_wrap_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
+                           "-I/opt/rocm/include", "-c", os.path.join(ROOT, "tests", "cpp", "jit_wrap_check.cpp"), "-o", obj])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-o", exe, obj] + objs + ["-lamd_comgr"])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "all cases OK" in text, text
+    assert text.count("identical") == 6
