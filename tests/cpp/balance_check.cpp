@@ -71,8 +71,12 @@ int main() {
     for (int m = 0; m < c.M; ++m)
       if (seen[m] != 1) { printf("channel %d dealt %d times\n", m, seen[m]); return 2; }
     const double o0 = objective(g, t, rowptr, colidx, ident), o1 = objective(g, t, rowptr, colidx, slot);
-    printf("C%d %dx%d M%d K%d dens %.2f %s: G=%d n_icb=%d  cost natural %.0f  dealt %.0f  (%.1f %%)\n", c.C, c.H, c.H,
-           c.M, c.K, c.dens, c.uneven ? "uneven" : "uniform", t.G, t.n_icb, o0, o1, 100.0 * (o1 / o0 - 1.0));
+    // (the table itself, as a hash: the deal is deterministic, and the incremental cost update that replaced the
+    // recompute-everything version must take exactly the swaps that one took -- tests/test_stream_builder.py pins them)
+    unsigned long long h = 1469598103934665603ull;
+    for (uint32_t v : slot) { h ^= v; h *= 1099511628211ull; }
+    printf("C%d %dx%d M%d K%d dens %.2f %s: G=%d n_icb=%d  cost natural %.0f  dealt %.0f  (%.1f %%)  table %016llx\n", c.C, c.H, c.H,
+           c.M, c.K, c.dens, c.uneven ? "uneven" : "uniform", t.G, t.n_icb, o0, o1, 100.0 * (o1 / o0 - 1.0), h);
     if (o1 > o0 * (1.0 + 1e-9)) ++bad;
   }
   if (bad) { printf("%d case(s) got worse\n", bad); return 1; }

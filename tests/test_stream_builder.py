@@ -5,6 +5,7 @@ shift-and-sum epilogue) and compared with a plain dense convolution on 35 geomet
 the machine code csrc/jit_codegen.cpp generates, run by an interpreter of its instruction forms -- unit by
 unit, and as whole-tile chains (waits, barriers, buffer rotation in code) where the generator chains them."""
 import os
+import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,3 +43,8 @@ def test_channel_deal_is_a_permutation_and_never_worse(tmp_path):
     text = out.stdout.decode()
     assert out.returncode == 0, text
     assert "all cases OK" in text
+    # ... and the tables are the ones the recompute-everything deal of rounds 2-4 produced (its incremental successor
+    # must take exactly the same swaps): seeded patterns, hashes of the slot -> channel tables
+    assert re.findall(r"table ([0-9a-f]{16})", text) == [
+        "a1ae34e0fa10ca7b", "fb941130f6083cb5", "c849f84ac359158b", "557a337c6eadb107", "31553581e755f76e", "1e0e07cf334fa7af",
+        "43eb030e59a267ff"]
