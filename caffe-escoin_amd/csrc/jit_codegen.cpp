@@ -2,8 +2,10 @@
 #include "jit_codegen.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace escoin {
 namespace jit {
@@ -251,86 +253,139 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
 
 }  // namespace
 
+namespace {
+// The units of one (conv group, oc-group) chain, as a blob of its own: unit offsets relative to its first byte, the
+// code touches' distances (all inside the chain: a unit touches its successor, the last one the first) patched in.
+struct ChainOut {
+  std::vector<uint32_t> code;
+  std::vector<uint32_t> off;        // [n_icb] byte offset of each unit's entry from the chain's first byte
+  long n_rows = 0, n_records = 0, n_dma = 0;
+  bool overflow = false;
+  size_t max_unit = 0;
+};
+
+void emit_chain(const ConvGeom &g, const Tiling &t, const std::vector<int> &rowptr, const std::vector<int> &colidx,
+                const std::vector<float> &values, const Options &opt, int n_pref, const uint32_t *chan, int ocg, ChainOut *out) {
+  ChainOut &p = *out;
+  const int rows_per_blk = t.icb * g.KH;
+  std::vector<Row> rows(rows_per_blk), live;
+  std::vector<Piece> pieces;
+  std::vector<size_t> patches;
+  p.off.assign(t.n_icb, 0u);
+  for (int blk = 0; blk < t.n_icb; ++blk) {
+    for (auto &r : rows) r.recs.clear();
+    const int ic_lo = blk * t.icb, ic_hi = std::min(g.Cg, ic_lo + t.icb);
+    for (int gl = 0; gl < t.G; ++gl) {
+      if (ocg * t.G + gl >= g.Mg) break;
+      const int m = (int)chan[gl];
+      // (columns ascend within a CSR row: the block's nonzeros are one contiguous run)
+      const int *b = colidx.data() + rowptr[m], *e = colidx.data() + rowptr[m + 1];
+      const int *lo = std::lower_bound(b, e, ic_lo * g.KH * g.KW), *hi = std::lower_bound(lo, e, ic_hi * g.KH * g.KW);
+      for (const int *cp = lo; cp < hi; ++cp) {
+        const int col = *cp;
+        const int kc = col % g.KW, kr = (col / g.KW) % g.KH, ic = col / (g.KW * g.KH);
+        Rec rec;
+        std::memcpy(&rec.bits, &values[(size_t)(cp - colidx.data())], 4);
+        rec.idx = gl * g.KW + kc;
+        rows[(ic - ic_lo) * g.KH + kr].recs.push_back(rec);
+      }
+    }
+    live.clear();
+    for (int r = 0; r < rows_per_blk; ++r) {
+      if (rows[r].recs.empty()) continue;
+      const int icl = r / g.KH, kr = r % g.KH;
+      const size_t off = ((size_t)icl * t.plane_ch_floats + (size_t)kr * t.nseg * t.RS) * 4;
+      if (off > 0xFFF0u) p.overflow = true;
+      Row row;
+      row.lds_off = (uint32_t)off;
+      row.recs.swap(rows[r].recs);
+      p.n_records += (long)row.recs.size();
+      live.push_back(std::move(row));
+    }
+    p.n_rows += (long)live.size();
+    // this wave's pieces of the block staged while this unit runs: block blk + ahead of this tile
+    // or, past its last block, of the workgroup's next tile
+    pieces.clear();
+    if (opt.dma.on) {
+      const DmaPlan &d = opt.dma;
+      const int wave = ocg % d.waves;
+      const int nb = (blk + d.ahead) % t.n_icb;
+      const int nch = std::min(t.icb, g.Cg - nb * t.icb);
+      const long total = (long)nch * d.qpc;
+      const int n_instr = (int)((total + 63) / 64);
+      const int ch_per_period = d.period / d.qpc;
+      for (int i = wave; i < n_instr; i += d.waves) {
+        const long e0 = (long)i * 64;
+        Piece pc;
+        pc.tab_off = (uint32_t)((e0 % d.period) * 4);
+        pc.lds_off = (uint32_t)i * 1024u;
+        pc.soff = (uint32_t)(((long)nb * t.icb + (e0 / d.period) * ch_per_period) * d.chan_bytes);
+        pc.lanes = (int)std::min<long>(64, total - e0);
+        pieces.push_back(pc);
+      }
+      p.n_dma += (long)pieces.size();
+    }
+    while ((p.code.size() * 4) % kUnitAlign) enc_nop(p.code);
+    p.off[blk] = (uint32_t)(p.code.size() * 4);
+    const size_t at = p.code.size();
+    patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref, t.pix_waves == 1 ? ocg % t.oc_waves : -1, blk, t.n_icb));
+    p.max_unit = std::max(p.max_unit, (p.code.size() - at) * 4);
+  }
+  // the distances: unit blk touches the code of unit (blk + 1) % n_icb
+  if (n_pref > 0)
+    for (int blk = 0; blk < t.n_icb; ++blk) {
+      const int nxt = (blk + 1) % t.n_icb;
+      const long long from = (long long)p.off[blk] + 4;        // what s_getpc_b64 returned
+      const long long d = (long long)p.off[nxt] - from;
+      p.code[patches[blk]] = (uint32_t)d;
+      if (d < 0) p.code[patches[blk] + 1] = 0x82000000u | ((uint32_t)(kSPref + 1) << 16) | (0xC1u << 8) | (uint32_t)(kSPref + 1);
+    }
+}
+}  // namespace
+
 static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,
                           const std::vector<std::vector<int>> &colidx,
                           const std::vector<std::vector<float>> &values, const Options &opt, int n_pref,
                           size_t *max_unit_bytes, const std::vector<uint32_t> &chan) {
   Program p;
-  std::vector<size_t> patches;
-  const size_t n_units = (size_t)g.group * t.n_ocg * t.n_icb;
+  const size_t n_chains = (size_t)g.group * t.n_ocg, n_units = n_chains * t.n_icb;
   p.unit_off.assign(n_units, 0u);
   p.chan = chan;
-  const int rows_per_blk = t.icb * g.KH;
-  std::vector<Row> rows(rows_per_blk), live;
-  std::vector<Piece> pieces;
-  for (int cg = 0; cg < g.group; ++cg)
-    for (int ocg = 0; ocg < t.n_ocg; ++ocg)
-      for (int blk = 0; blk < t.n_icb; ++blk) {
-        for (auto &r : rows) r.recs.clear();
-        const int ic_lo = blk * t.icb, ic_hi = std::min(g.Cg, ic_lo + t.icb);
-        for (int gl = 0; gl < t.G; ++gl) {
-          if (ocg * t.G + gl >= g.Mg) break;
-          const int m = (int)p.chan[((size_t)cg * t.n_ocg + ocg) * t.G + gl];
-          for (int j = rowptr[cg][m]; j < rowptr[cg][m + 1]; ++j) {
-            const int col = colidx[cg][j];
-            const int kc = col % g.KW, kr = (col / g.KW) % g.KH, ic = col / (g.KW * g.KH);
-            if (ic < ic_lo || ic >= ic_hi) continue;
-            Rec rec;
-            std::memcpy(&rec.bits, &values[cg][j], 4);
-            rec.idx = gl * g.KW + kc;
-            rows[(ic - ic_lo) * g.KH + kr].recs.push_back(rec);
-          }
-        }
-        live.clear();
-        for (int r = 0; r < rows_per_blk; ++r) {
-          if (rows[r].recs.empty()) continue;
-          const int icl = r / g.KH, kr = r % g.KH;
-          const size_t off = ((size_t)icl * t.plane_ch_floats + (size_t)kr * t.nseg * t.RS) * 4;
-          if (off > 0xFFF0u) p.overflow = true;
-          Row row;
-          row.lds_off = (uint32_t)off;
-          row.recs = rows[r].recs;
-          p.n_records += (long)row.recs.size();
-          live.push_back(std::move(row));
-        }
-        p.n_rows += (long)live.size();
-        // this wave's pieces of the block staged while this unit runs: block blk + ahead of this tile
-        // or, past its last block, of the workgroup's next tile
-        pieces.clear();
-        if (opt.dma.on) {
-          const DmaPlan &d = opt.dma;
-          const int wave = ocg % d.waves;
-          const int nb = (blk + d.ahead) % t.n_icb;
-          const int nch = std::min(t.icb, g.Cg - nb * t.icb);
-          const long total = (long)nch * d.qpc;
-          const int n_instr = (int)((total + 63) / 64);
-          const int ch_per_period = d.period / d.qpc;
-          for (int i = wave; i < n_instr; i += d.waves) {
-            const long e0 = (long)i * 64;
-            Piece pc;
-            pc.tab_off = (uint32_t)((e0 % d.period) * 4);
-            pc.lds_off = (uint32_t)i * 1024u;
-            pc.soff = (uint32_t)(((long)nb * t.icb + (e0 / d.period) * ch_per_period) * d.chan_bytes);
-            pc.lanes = (int)std::min<long>(64, total - e0);
-            pieces.push_back(pc);
-          }
-          p.n_dma += (long)pieces.size();
-        }
-        while ((p.code.size() * 4) % kUnitAlign) enc_nop(p.code);
-        p.unit_off[((size_t)cg * t.n_ocg + ocg) * t.n_icb + blk] = (uint32_t)(p.code.size() * 4);
-        const size_t at = p.code.size();
-        patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref, t.pix_waves == 1 ? ocg % t.oc_waves : -1, blk, t.n_icb));
-        *max_unit_bytes = std::max(*max_unit_bytes, (p.code.size() - at) * 4);
-      }
-  // the distances: unit (cg, ocg, blk) touches the code of (cg, ocg, (blk + 1) % n_icb)
-  if (n_pref > 0)
-    for (size_t ui = 0; ui < n_units; ++ui) {
-      const size_t blk = ui % t.n_icb, nxt = ui - blk + (blk + 1) % t.n_icb;
-      const long long from = (long long)p.unit_off[ui] + 4;        // what s_getpc_b64 returned
-      const long long d = (long long)p.unit_off[nxt] - from;
-      p.code[patches[ui]] = (uint32_t)d;
-      if (d < 0) p.code[patches[ui] + 1] = 0x82000000u | ((uint32_t)(kSPref + 1) << 16) | (0xC1u << 8) | (uint32_t)(kSPref + 1);
-    }
+  // the chains are independent (a unit's touches stay inside its chain): large layers generate them on up to eight
+  // threads, and the blobs are put together in order -- the same bytes as one thread would write
+  std::vector<ChainOut> outs(n_chains);
+  auto run = [&](size_t ci) {
+    const int cg = (int)(ci / t.n_ocg), ocg = (int)(ci % t.n_ocg);
+    emit_chain(g, t, rowptr[cg], colidx[cg], values[cg], opt, n_pref, &p.chan[ci * t.G], ocg, &outs[ci]);
+  };
+  size_t nnz = 0;
+  for (const auto &c : colidx) nnz += c.size();
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t n_thr = nnz >= 20000 && n_chains > 1 ? std::min<size_t>(std::min<size_t>(8, hw), n_chains) : 1;
+  if (n_thr <= 1) {
+    for (size_t ci = 0; ci < n_chains; ++ci) run(ci);
+  } else {
+    std::vector<std::thread> pool;
+    std::atomic<size_t> next{0};
+    for (size_t th = 0; th < n_thr; ++th)
+      pool.emplace_back([&]() {
+        for (size_t i = next.fetch_add(1); i < n_chains; i = next.fetch_add(1)) run(i);
+      });
+    for (auto &th : pool) th.join();
+  }
+  size_t total = 0;
+  for (const ChainOut &c : outs) total += c.code.size() + kUnitAlign / 4;
+  p.code.reserve(total + 64 + (size_t)n_pref * 1024);
+  for (size_t ci = 0; ci < n_chains; ++ci) {
+    const ChainOut &c = outs[ci];
+    while ((p.code.size() * 4) % kUnitAlign) enc_nop(p.code);
+    const uint32_t base = (uint32_t)(p.code.size() * 4);
+    p.code.insert(p.code.end(), c.code.begin(), c.code.end());
+    for (int blk = 0; blk < t.n_icb; ++blk) p.unit_off[ci * t.n_icb + blk] = base + c.off[blk];
+    p.n_rows += c.n_rows; p.n_records += c.n_records; p.n_dma += c.n_dma;
+    p.overflow = p.overflow || c.overflow;
+    *max_unit_bytes = std::max(*max_unit_bytes, c.max_unit);
+  }
   // instruction prefetch and the code touches run past the last unit: keep them inside the blob
   for (int i = 0; i < 64 + n_pref * 1024; ++i) enc_nop(p.code);
   p.n_pref = n_pref;
