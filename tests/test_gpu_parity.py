@@ -953,3 +953,24 @@ def test_strided_pointwise_layers(pkg, oracle, synth, torch_cuda):
     top = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev))
     assert rel_err(top.cpu().numpy(), oracle.conv_forward(g, x, w, b, gate=False)) <= TOL
     plan.close()
+
+
+def test_plan_churn_gives_its_device_memory_back(pkg, synth, torch_cuda):
+    """Plans created, aligned (generated code: a code object loaded per layer), run once and destroyed, round after
+    round: what a plan takes on the device -- CSR, unit tables, the loaded code object -- goes back when it is
+    destroyed (the reference frees its layer-private buffers in the destructor, base_conv_layer.cpp:16-42)."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    shapes = synth.resnet50_3x3(N=4) + synth.googlenet_1x1(N=4)[:4] + synth.alexnet(N=4)[:1]
+    free = []
+    for it in range(5):
+        for s in shapes:
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_AUTO)
+            plan.weight_align(synth.pruned_weights(s, 10 + it))
+            x = torch.rand((s.N, s.C, s.H, s.W), device=dev)
+            plan.forward(x, None)
+            del plan
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    # (the first round warms torch's caching allocator and the HIP runtime; after it nothing may accumulate)
+    assert max(free[1:]) - min(free[1:]) <= 8 << 20, free
