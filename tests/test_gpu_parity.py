@@ -974,3 +974,49 @@ def test_plan_churn_gives_its_device_memory_back(pkg, synth, torch_cuda):
         free.append(torch.cuda.mem_get_info()[0])
     # (the first round warms torch's caching allocator and the HIP runtime; after it nothing may accumulate)
     assert max(free[1:]) - min(free[1:]) <= 8 << 20, free
+
+
+def test_plans_of_two_host_threads_on_two_streams(pkg, oracle, synth, torch_cuda):
+    """a layer instance belongs to one host thread; several threads, each with its own plans and its own
+    stream, share the device.  Two threads WeightAlign (code generation, the process-wide code object template, module
+    loads) and run their layers at the same time, repeatedly; every output is checked against the oracle."""
+    import threading
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    sets = [synth.resnet50_3x3(N=3) + synth.alexnet(N=3)[:2], [synth.googlenet_1x1(N=3)[i] for i in (0, 5, 9, 25, 33)] + synth.lenet_conv2(N=3)]
+    jobs = []
+    for t, shapes in enumerate(sets):
+        for k, s in enumerate(shapes):
+            w, b, x = synth.pruned_weights(s, 500 + 10 * t + k), synth.bias_vector(s, 600 + k), synth.activations(s, 700 + k)
+            g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, s.dil_h, s.dil_w, s.group)
+            jobs.append((t, s, w, b, x, oracle.conv_forward(g, x, w, b, gate=False, threads=4)))
+    errors = []
+    start = threading.Barrier(2)
+
+    def worker(t):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            start.wait()
+            with torch.cuda.stream(stream):
+                for rep in range(3):
+                    for (tt, s, w, b, x, want) in jobs:
+                        if tt != t:
+                            continue
+                        plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_AUTO)
+                        plan.weight_align(w)
+                        xd = torch.from_numpy(x).to(dev, non_blocking=False)
+                        bd = torch.from_numpy(b).to(dev) if b is not None else None
+                        got = plan.forward(xd, bd)
+                        stream.synchronize()
+                        e = rel_err(got.cpu().numpy(), want)
+                        if e > TOL:
+                            errors.append("%s (thread %d, round %d): %g" % (s.name, t, rep, e))
+        except Exception as exc:      # noqa: BLE001 -- reported to the main thread
+            errors.append("thread %d: %r" % (t, exc))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not errors, errors
