@@ -288,6 +288,11 @@ def test_bias_null_relu_and_partial_batch(pkg, oracle, synth, torch_cuda):
         torch.cuda.synchronize()
         t = top.cpu().numpy()
         assert rel_err(t[:2], nb[:2]) <= 1e-6 and (t[2:] == 7.0).all()
+        # ... and an empty batch is a legal no-op
+        top.fill_(9.0)
+        plan.forward_ptr(xd.data_ptr(), 0, top.data_ptr(), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert (top.cpu().numpy() == 9.0).all()
         with pytest.raises(pkg.EscoinError):
             plan.forward_ptr(xd.data_ptr(), 0, top.data_ptr(), 6, None)   # > desc.N
         plan.close()
