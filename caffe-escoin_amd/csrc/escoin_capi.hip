@@ -272,6 +272,60 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
     if (!p->tiled.enabled && p->kernel_choice == ESCOIN_KERNEL_TILED)
       return fail(ESCOIN_EINVAL, "tiled kernel requested but its weight stream does not fit the LDS budget");
   }
+  // Small launches.  The LDS-tiled kernels walk a tile block by block, every block a round trip to HBM, on as many
+  // workgroups as the batch has tiles x columns: 11-19 us for one image of a GoogLeNet 1x1 layer; the generic kernel
+  // puts a lane on every output pixel of the whole chip and needs 7-12 (profiles/r04_batch_sweep.md -- the reference's
+  // SCONV mode calls the layer image by image, conv_layer.cu:16-26).  Where the whole launch is under 64 MFLOP,
+  // KERNEL_AUTO therefore TIMES both kernels at WeightAlign -- zero-filled scratch blobs of the plan's batch, four
+  // launches each -- and keeps the generic kernel if it is more than a tenth faster.  ESCOIN_AUTO_TUNE=0: never.
+  static const bool auto_tune = !(getenv("ESCOIN_AUTO_TUNE") && atoi(getenv("ESCOIN_AUTO_TUNE")) == 0);
+  p->tuned_small = 0;
+  // (not for a plan whose tiling was asked for another batch, option "tiling_batch": its launches are not the ones
+  // the tiling is meant for)
+  if (auto_tune && p->kernel_choice == ESCOIN_KERNEL_AUTO && p->tiled.enabled && p->n_dense_groups == 0 &&
+      (p->tiling_batch <= 0 || p->tiling_batch == g.d.N)) {
+    long nnz_all = 0;
+    for (int grp = 0; grp < G; ++grp) nnz_all += (long)p->colidx[grp].size();
+    const double flops = 2.0 * g.d.N * g.OH * g.OW * (double)nnz_all;
+    if (flops < 64e6) {
+      const size_t in_bytes = sizeof(float) * (size_t)g.d.N * g.d.C * g.d.H * g.d.W;
+      const size_t out_bytes = sizeof(float) * (size_t)g.d.N * g.d.M * g.OH * g.OW;
+      float *scratch_in = nullptr, *scratch_out = nullptr;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      float ms_fast = 0.f, ms_gen = 0.f;
+      bool ok = hipMalloc(&scratch_in, in_bytes) == hipSuccess && hipMalloc(&scratch_out, out_bytes) == hipSuccess &&
+                hipMemsetAsync(scratch_in, 0, in_bytes, stream) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+                hipEventCreate(&e1) == hipSuccess;
+      p->aligned = true;       // (the launch functions check nothing else of the plan's state)
+      for (int which = 0; ok && which < 2; ++which) {
+        auto run = [&]() {
+          return which == 0 ? launch_tiled(p, scratch_in, nullptr, scratch_out, g.d.N, stream)
+                            : launch_generic(p, scratch_in, nullptr, scratch_out, g.d.N, stream);
+        };
+        ok = run() == ESCOIN_OK && hipEventRecord(e0, stream) == hipSuccess;
+        for (int k = 0; ok && k < 4; ++k) ok = run() == ESCOIN_OK;
+        ok = ok && hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(which == 0 ? &ms_fast : &ms_gen, e0, e1) == hipSuccess;
+      }
+      p->aligned = false;
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (scratch_in) (void)hipFree(scratch_in);
+      if (scratch_out) (void)hipFree(scratch_out);
+      if (ok) {
+        p->tuned_small = ms_gen < 0.9f * ms_fast ? 2 : 1;
+        if (getenv("ESCOIN_VERBOSE"))
+          fprintf(stderr, "[escoin] small launch (%.1f MFLOP): tiled %.1f us, generic %.1f us -> %s\n", flops * 1e-6,
+                  ms_fast * 250.0, ms_gen * 250.0, p->tuned_small == 2 ? "generic" : "tiled");
+        if (p->tuned_small == 2) {
+          const float dens = p->tiled.density;
+          tiled_release(p);
+          p->tiled.density = dens;
+        }
+      }
+      // (a failure of the measurement is not the layer's failure: the tiled kernel stays)
+    }
+  }
   p->kernel_name = p->tiled.enabled ? tiled_kernel_name(p) : generic_kernel_name(g.d.fuse_relu != 0);
   if (p->n_dense_groups > 0) p->kernel_name += std::string(" + ") + dense_kernel_name();
   p->aligned = true;
@@ -551,6 +605,7 @@ long escoin_plan_stat(const escoin_plan *p, const char *key) {
   if (!strcmp(key, "code_bytes")) return (long)(p->tiled.enabled && p->tiled.jit ? p->jit_module.code_bytes : 0);
   if (!strcmp(key, "device_bytes")) return (long)p->device_bytes;
   if (!strcmp(key, "import_fast")) return p->import_fast ? 1 : 0;
+  if (!strcmp(key, "tuned_small")) return p->tuned_small;
   if (!strcmp(key, "jit_rows")) return p->tiled.jit ? p->tiled.jit_rows : 0;
   if (!strcmp(key, "jit_records")) return p->tiled.jit ? p->tiled.jit_records : 0;
   if (!strcmp(key, "lds_bytes")) return p->tiled.enabled ? (long)p->tiled.lds_bytes : 0;

@@ -99,6 +99,7 @@ struct escoin_plan {
   std::vector<uint32_t> h_unit_off, h_chan;
   double align_ms = 0.0;          // wall time of the last weight_align / set_csr / import_aligned
   bool import_fast = false;       // the last import_aligned loaded a persisted code object as it was
+  int tuned_small = 0;             // KERNEL_AUTO timed the tiled and the generic kernel on a small launch: 1 kept tiled, 2 took generic
 
   // dense fallback (fp32 MFMA implicit GEMM), chosen per conv group: bit g of dense_mask = group g
   // goes to the MFMA kernel, bit g of sparse_mask = to the sparse kernels (layers with more than 64

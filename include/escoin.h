@@ -173,7 +173,10 @@ ESCOIN_API int escoin_plan_import_aligned(escoin_plan *plan, const void *buf, si
 /* Integer facts about an aligned plan (negative = error): "align_us" wall time of the last
  * weight_align / set_csr / import_aligned, "code_bytes" generated machine code on the device,
  * "device_bytes", "import_fast", "jit_rows", "jit_records", "lds_bytes", "workgroup_columns",
- * "kernel_choice" (the ESCOIN_KERNEL_* id AUTO resolved to for the sparse groups). */
+ * "kernel_choice" (the ESCOIN_KERNEL_* id AUTO resolved to for the sparse groups), "tuned_small" (KERNEL_AUTO
+ * timed the LDS-tiled and the generic kernel at WeightAlign because the whole launch is under 64 MFLOP -- the
+ * reference's SCONV mode runs image by image, conv_layer.cu:16-26 --: 0 no, 1 and kept the tiled one, 2 and took
+ * the generic one). */
 ESCOIN_API long escoin_plan_stat(const escoin_plan *plan, const char *key);
 
 /* Name of the device kernel the plan launches (the symbol rocprofv3 reports). */
