@@ -1066,3 +1066,33 @@ def test_kernel_auto_times_small_launches(pkg, oracle, synth, torch_cuda):
     plan.weight_align(synth.pruned_weights(s256, 1))
     assert plan.stat("tuned_small") == 0 and _fast(plan.kernel_name)
     plan.close()
+
+
+def test_blobs_that_start_off_a_16_byte_boundary(pkg, oracle, synth, torch_cuda):
+    """A caller may hand in any float-aligned pointer (the reference's SCONV mode passes `bottom_data + n * bottom_dim_`,
+    conv_layer.cu:16-26; a 13 x 13 x 3 image is 2028 bytes): bottom and top one, two and three floats past a 16-byte
+    boundary, on every kernel family, with widths that are and are not whole quads."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    cases = [synth.shape("k3", 3, 16, 14, 14, 24, 3, pad=1, sparsity=0.85), synth.shape("k1", 3, 40, 14, 14, 32, 1, sparsity=0.9),
+             synth.shape("k3w13", 2, 8, 13, 13, 16, 3, pad=1, sparsity=0.8), synth.shape("k5", 2, 8, 27, 27, 16, 5, pad=2, sparsity=0.8)]
+    for k, s in enumerate(cases):
+        w, b, x = synth.pruned_weights(s, 40 + k), synth.bias_vector(s, 50 + k), synth.activations(s, 60 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w)
+        want = oracle.conv_forward(g, x, w, b, gate=False)
+        for kernel in _kernels(pkg, pkg.ConvDesc.from_shape(s)) + [pkg.KERNEL_DENSE]:
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel)
+            plan.weight_align(w)
+            bd = torch.from_numpy(b).to(dev)
+            for off in (1, 2, 3):
+                xin = torch.zeros(x.size + 8, device=dev)
+                xin[off:off + x.size] = torch.from_numpy(x).to(dev).reshape(-1)
+                out = torch.full((want.size + 8,), 5.0, device=dev)
+                plan.forward_ptr(xin.data_ptr() + 4 * off, bd.data_ptr(), out.data_ptr() + 4 * off, s.N,
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                o = out.cpu().numpy()
+                got = o[off:off + want.size].reshape(want.shape)
+                assert rel_err(got, want) <= TOL, "%s via %s, %d floats off: %g" % (s.name, plan.kernel_name, off, rel_err(got, want))
+                assert (o[:off] == 5.0).all() and (o[off + want.size:] == 5.0).all(), (s.name, plan.kernel_name, off)
+            plan.close()
