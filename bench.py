@@ -121,11 +121,15 @@ def device_images(be, shape, shape_index, g0, n):
     return x
 
 
+# how the nonzeros of the synthetic weights lie (--sparsity-dist; synth.SPARSITY_DISTS): "uniform" = every BASELINE config
+WEIGHT_DIST = "uniform"
+
+
 def layer_weight_seed(lid):
     return 1000 + 31 * lid
 
 
-def build_layers(be, pkg, synth, shapes, rank, world, args=None):
+def build_layers(be, pkg, synth, shapes, rank, world, args=None, dist_on=None):
     """WeightAlign on rank 0, broadcast of the CSR (RCCL on the GPU box), set_csr elsewhere.
     Returns [(shape, plan, bias, shape_index, layer_id)] and the one-time costs: seconds in the
     broadcast, per-layer WeightAlign milliseconds (rank 0: dense -> CSR -> tiling, channel deal,
@@ -133,18 +137,41 @@ def build_layers(be, pkg, synth, shapes, rank, world, args=None):
     dense -> CSR), generated-code bytes."""
     torch = be.torch
     layers, t_bcast, lid = [], 0.0, 0
-    setup = {"align_ms": [], "receive_ms": [], "code_bytes": 0, "device_bytes": 0}
+    setup = {"align_ms": [], "receive_ms": [], "code_bytes": 0, "device_bytes": 0, "first_load_ms": None}
+    if dist_on is None:
+        dist_on = world > 1
+    # --force-dist on ONE rank: the process group, the broadcast and the receiver's import all run (rank 0 is its own
+    # receiver: it imports the blob it broadcast into a second plan, and THAT plan is the one the step times)
+    loopback = dist_on and world == 1
+    if rank == 0 and hasattr(pkg, "Plan") and not test_be(be):
+        # The process's first WeightAlign of a generated-code plan also assembles the code object template (once per
+        # process, jit_module.cpp) and loads the process's first HIP module: ~90-120 ms that belong to the process,
+        # not to a layer.  A throw-away plan of the first layer's shape pays them here, timed on its own line.
+        s0 = shapes[0]
+        t0 = time.perf_counter()
+        warm = be.make_plan(s0)
+        warm.weight_align(synth.pruned_weights(s0, layer_weight_seed(0), WEIGHT_DIST))
+        be.synchronize()
+        t_first = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        again = be.make_plan(s0)
+        again.weight_align(synth.pruned_weights(s0, layer_weight_seed(0), WEIGHT_DIST))
+        be.synchronize()
+        t_again = (time.perf_counter() - t0) * 1e3
+        warm.close()
+        again.close()
+        setup["first_load_ms"] = max(0.0, t_first - t_again)
     for si, s in enumerate(shapes):
         for rep in range(s.count):
             plan = be.make_plan(s)
             mg = s.M // s.group
             if rank == 0:
-                w = synth.pruned_weights(s, layer_weight_seed(lid))
+                w = synth.pruned_weights(s, layer_weight_seed(lid), WEIGHT_DIST)
                 t0 = time.perf_counter()
                 plan.weight_align(w)
                 be.synchronize()
                 setup["align_ms"].append((time.perf_counter() - t0) * 1e3)
-            if world > 1:
+            if dist_on:
                 be.synchronize()
                 t0 = time.perf_counter()
                 # what travels: the ALIGNED form (CSR + channel deal + unit table + code object, one blob:
@@ -160,7 +187,10 @@ def build_layers(be, pkg, synth, shapes, rank, world, args=None):
                                                   src=0, device=be.device)
                 be.synchronize()
                 t_bcast += time.perf_counter() - t0
-                if rank != 0:
+                if rank != 0 or loopback:
+                    if loopback:
+                        plan.close()
+                        plan = be.make_plan(s)
                     t0 = time.perf_counter()
                     if aligned:
                         setup["import_fast"] = setup.get("import_fast", 0) + int(plan.import_aligned(got))
@@ -201,7 +231,7 @@ def parity_check(be, oracle, synth, layers, bottoms, tops, images_per_shape=3):
         got = tops[li][idx].cpu().numpy()
         g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
                         s.dil_h, s.dil_w, s.group)
-        w = synth.pruned_weights(s, layer_weight_seed(lid))
+        w = synth.pruned_weights(s, layer_weight_seed(lid), WEIGHT_DIST)
         b = synth.bias_vector(s, 2000 + 31 * lid)
         want = oracle.conv_forward(g, x, w, b, gate=False, threads=min(8, len(imgs)))
         err = float(np.abs(got.astype(np.float64) - want).max() / max(1e-6, float(np.abs(want).max())))
@@ -213,7 +243,7 @@ def cross_rank_check(be, dist, synth, layers, shapes, tops, rank, world, g0_of_r
     """Per-image checksums of every rank's outputs are gathered; rank 0 recomputes the first and
     last image of every OTHER rank's shard (same global-index seeds, its own plans) and compares.
     Returns the worst relative checksum difference (None for world == 1)."""
-    if world == 1:
+    if dist is None:
         return None
     torch = be.torch
     worst = 0.0
@@ -311,7 +341,7 @@ def cpu_baseline(oracle, synth, shapes, budget_s):
     for k, s in enumerate(shapes):
         g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w,
                         s.dil_h, s.dil_w, s.group)
-        w = synth.pruned_weights(s, 1000 + k)
+        w = synth.pruned_weights(s, 1000 + k, WEIGHT_DIST)
         b = synth.bias_vector(s, 2000 + k)
         plan = oracle.RefPlan(g, w) if use_ref else None
         blocked_ok = blocked_ok and plan is not None and plan.has_blocked
@@ -430,7 +460,8 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         g0_of_rank = [r * per_gpu_batch for r in range(world)]
     global_batch = sum(per_rank)
 
-    layers, t_bcast, setup = build_layers(be, pkg, synth, shapes, rank, world, args)
+    dist_on = dist is not None          # world > 1, or one rank under --force-dist
+    layers, t_bcast, setup = build_layers(be, pkg, synth, shapes, rank, world, args, dist_on)
 
     # ---- synthetic activations resident in HBM (image k seeded by its GLOBAL index) -----------
     # Every LAYER has its own bottom / top pair (layers of one shape get copies of the same
@@ -504,7 +535,7 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     for rep in range(max(1, args.repeats)):
         step_ev = [be.event() for _ in range(args.steps + 1)]
         ev = {k: [step_ev[k]] + [be.event() for _ in range(len(layers))] for k in sampled}
-        if world > 1:
+        if dist_on:
             dist.barrier()
         be.synchronize()
         t0 = time.perf_counter()
@@ -514,7 +545,7 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         step_ev[args.steps].record()
         be.synchronize()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             dist.barrier()
             t = torch.tensor([elapsed], device=be.device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -528,15 +559,16 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     # ---- self-check of what was just computed (outside the timed region) ----------------------
     oracle = oracle_loader()
     parity = parity_check(be, oracle, synth, layers, bottoms, tops)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([parity], device=be.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         parity = float(t.item())
     cross = cross_rank_check(be, dist, synth, layers, shapes, tops, rank, world, g0_of_rank, per_rank)
     receive = None
-    if world > 1:
-        # the slowest receiver's set_csr total and its slowest layer (rank 0 has none: it aligned)
-        t = torch.tensor([sum(setup["receive_ms"]), max(setup["receive_ms"] or [0.0]), -float(setup.get("import_fast", 0)) if rank else -1e9],
+    if dist_on:
+        # the slowest receiver's set_csr total and its slowest layer (rank 0 has none: it aligned -- unless it is its
+        # own receiver, --force-dist on one rank)
+        t = torch.tensor([sum(setup["receive_ms"]), max(setup["receive_ms"] or [0.0]), -float(setup.get("import_fast", 0)) if (rank or world == 1) else -1e9],
                          device=be.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         receive = {"total": round(float(t[0].item()), 2), "max_per_layer": round(float(t[1].item()), 2),
@@ -658,20 +690,26 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         "config": {"workload": "%s @%d%% sparsity, batch %d/GPU, fp32" %
                                (wl_name, round(100 * shapes[0].sparsity), per_gpu_batch),
                    "global_batch": global_batch, "layers_per_step": len(layers),
+                   "sparsity_dist": getattr(args, "sparsity_dist", "uniform"),
                    "kernel": args.kernel, "stream_stores": bool(getattr(args, "stream_stores", False)),
                    "streams": n_streams,
                    "parallelism": "batch-sharded x%d" % world,
-                   "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None},
-        "weight_broadcast_ms": round(t_bcast * 1e3, 3) if world > 1 else None,
+                   "weight_broadcast_ms": round(t_bcast * 1e3, 3) if dist_on else None},
+        "weight_broadcast_ms": round(t_bcast * 1e3, 3) if dist_on else None,
         # one-time costs outside the timed region (the reference's WeightAlign runs once per weight load,
         # net.cpp:819): rank 0's WeightAlign per layer -- it now generates and assembles code --, the
         # generated code's size, and (N > 1) what a RECEIVER spends in set_csr after the broadcast
+        # (`first_load_ms`: what the process's FIRST generated-code WeightAlign costs on top of a second one of the same
+        #  layer -- the code object template assembled once per process and the first HIP module load -- paid by a
+        #  throw-away plan before the layers are aligned, so the per-layer figures are the layers' own)
         "weight_align_ms": {"total": round(sum(setup["align_ms"]), 2),
                             "max_per_layer": round(max(setup["align_ms"]), 2) if setup["align_ms"] else None,
+                            "per_layer": [round(v, 2) for v in setup["align_ms"]],
+                            "first_load_ms": None if setup.get("first_load_ms") is None else round(setup["first_load_ms"], 2),
                             "layers": len(setup["align_ms"])},
         "generated_code_bytes": setup["code_bytes"], "plan_device_bytes": setup["device_bytes"],
         "weight_receive_ms": receive,
-        "backend": be.name, "dist_backend": (be.dist_backend if test_be(be) else args.dist_backend) if world > 1 else None,
+        "backend": be.name, "dist_backend": (be.dist_backend if test_be(be) else args.dist_backend) if dist_on else None,
         "buffers": "one bottom/top pair per layer (no launch re-reads the previous launch's input)",
         "parity_max_rel_err": float("%.3g" % parity),
         "cross_rank_checksum_rel_diff": None if cross is None else float("%.3g" % cross),
@@ -700,6 +738,12 @@ def parse_args(argv=None):
     ap.add_argument("--global-batch", type=int, default=None,
                     help="total images over all GPUs (strong scaling; BASELINE configs[3]: 2048)")
     ap.add_argument("--sparsity", type=float, default=None)
+    ap.add_argument("--sparsity-dist", default="uniform",
+                    choices=["uniform", "channel", "zero_inputs", "filters_tail", "i", "ii", "iii"],
+                    help="how the nonzeros lie at the same total count: uniform (the BASELINE configs); i = channel: "
+                         "per-output-channel density ~U(0, 2d); ii = zero_inputs: 20 %% of the input channels all zero; "
+                         "iii = filters_tail: 10 %% of the filters all zero and 5 %% of the rows at 4d -- what a pruned "
+                         "model looks like (the reference's nets are SkimCaffe-pruned, run.sh:14)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "tiled", "jit"],
                     help="auto = generated code (jit) where available; tiled = the LDS-staged stream kernel")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds for the cpu_baseline leg")
@@ -714,9 +758,17 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=1,
                     help="issue the step's (independent) layers round robin on this many HIP streams; 1 = one stream, as "
                          "the reference launches its layers (the default and the judged line)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the distributed code path whatever --gpus says: with --gpus 1, ONE rank under "
+                         "torch.distributed.run goes through init_process_group (RCCL), the weight broadcast, export / "
+                         "import of the aligned form (rank 0 is its own receiver), the barriers, the MAX reduction and the "
+                         "cross-rank check -- the RCCL path on the hardware a one-GPU box has")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the driver's runs); gloo lets two ranks share one GPU for a rehearsal")
     args = ap.parse_args(argv)
+    args.sparsity_dist = {"i": "channel", "ii": "zero_inputs", "iii": "filters_tail"}.get(args.sparsity_dist, args.sparsity_dist)
+    global WEIGHT_DIST
+    WEIGHT_DIST = args.sparsity_dist
     k, w = DEFAULT_STEPS.get(args.workload, (100, 20))
     if args.steps is None:
         args.steps = k
@@ -778,7 +830,7 @@ def main(backend_factory=None, script=None):
     `python bench.py` itself knows one backend, the HIP library."""
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
-    if args.gpus > 1 and world_env is None:
+    if (args.gpus > 1 or args.force_dist) and world_env is None:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], script))      # nothing below runs in the launcher
     # the host's CPU share is read BEFORE any OpenMP runtime exists: with OMP_PROC_BIND set, the
     # runtime torch loads pins this thread to one core and the affinity mask then reads "2 threads"
@@ -803,18 +855,19 @@ def main(backend_factory=None, script=None):
         args.dist_backend = be.dist_backend
     else:
         be = HipBackend(pkg, local_rank, kernel, stream_stores=args.stream_stores)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=be.device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = run(args, be, pkg, synth, ge.load_oracle, dist if world > 1 else None)
+    out = run(args, be, pkg, synth, ge.load_oracle, dist if dist_on else None)
     if out is not None:
         if backend_factory is not None:
             out["test_backend"] = True
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     # wrong results are not a throughput: the line above carries "parity_failed", the exit code says it too

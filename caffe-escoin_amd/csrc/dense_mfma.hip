@@ -33,6 +33,13 @@
 #include <vector>
 
 #include "escoin_plan.h"
+#include "knobs.h"
+
+#ifdef ESCOIN_ABLATIONS
+#define ESC_DENSE_ABL(a, bits) ((a).abl & (bits))
+#else
+#define ESC_DENSE_ABL(a, bits) (0)
+#endif
 
 namespace escoin {
 
@@ -61,6 +68,7 @@ struct DenseArgs {
   // words (zeroed by the launch function before every launch) carry 1
   float *sk_ws;
   unsigned *sk_flag;     // [0 .. gridDim.x): published flags; [gridDim.x]: set when a bounded spin gave up
+  unsigned *sk_fail;     // the same give-up, sticky, in pinned HOST memory: the next escoin_forward on the plan fails loudly
 };
 
 __device__ __forceinline__ int a_swizzle(int row, int chunk) { return row * kBK + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -237,12 +245,12 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
     for (int ks = k_lo; ks < k_hi; ++ks, buf ^= 1) {
       // this wave's pieces of the step have landed (and the stores of the last epilogue are out) ...
 #ifdef ESCOIN_ABLATIONS
-      if (!(a.abl & 1))     // ESCOIN_DENSE_ABL: 1 no wait for the operands, 2 no operand traffic, 4 no MFMAs
+      if (!ESC_DENSE_ABL(a, 1))     // ESCOIN_DENSE_ABL: 1 no wait for the operands, 2 no operand traffic, 4 no MFMAs
 #endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();   // ... everyone's have, and everyone is done with the other buffer
 #ifdef ESCOIN_ABLATIONS
-      if (!(a.abl & 2))
+      if (!ESC_DENSE_ABL(a, 2))
 #endif
       if (in_run(f_tile)) {
         fetch(f_k, buf ^ 1);
@@ -273,7 +281,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         // scheduler sinks each read to just above its use and every 4 MFMAs wait for LDS)
         __builtin_amdgcn_sched_barrier(0);
 #ifdef ESCOIN_ABLATIONS
-        if (a.abl & 4) continue;
+        if (ESC_DENSE_ABL(a, 4)) continue;
 #endif
         const float a0[4] = {fa[s][0].x, fa[s][0].y, fa[s][0].z, fa[s][0].w};
         const float a1[4] = {fa[s][1].x, fa[s][1].y, fa[s][1].z, fa[s][1].w};
@@ -321,12 +329,19 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         const long tile_lo = tile * (long)nk;
         for (long w = (long)blockIdx.x - 1; w >= 0 && (w + 1) * sk_q > tile_lo; --w) {
           if (wave == 0) {
-            // ONE wave polls ONE word, relaxed, bounded (a stuck launch must end: the give-up word makes the host fail)
+            // ONE wave polls ONE word, relaxed, bounded (a stuck launch must end: the give-up word makes the host fail).
+            // Forward progress: the producer is a workgroup with a LOWER blockIdx.x; workgroups are dispatched in
+            // index order and the grid never exceeds the resident slots (2 x CUs), so every producer is resident
+            // or finished when its consumer polls.  If a runtime ever dispatched out of order on a partly occupied
+            // device, the bounded spin ends the launch and the sticky word below turns it into an error.
             unsigned spins = 0;
             while (__hip_atomic_load((gu32 *)(a.sk_flag + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
               __builtin_amdgcn_s_sleep(2);
               if (++spins > (1u << 24)) {
-                if (lane == 0) __hip_atomic_store((gu32 *)(a.sk_flag + gridDim.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                  __hip_atomic_store((gu32 *)(a.sk_flag + gridDim.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store((gu32 *)a.sk_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 break;
               }
             }
@@ -507,14 +522,11 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
                          g.d.pad_h == 0 && g.d.pad_w == 0;
   const bool vec_b = pointwise && (g.d.H * g.d.W) % 4 == 0 && (reinterpret_cast<uintptr_t>(bottom) & 15) == 0 && P >= 4;
   {
-    static const bool vo = !(getenv("ESCOIN_DENSE_VEC_OUT") && atoi(getenv("ESCOIN_DENSE_VEC_OUT")) == 0);
+    static const bool vo = (ESC_KNOB("DENSE_VEC_OUT", 1) != 0);
     a.vec_out = vo && (g.OH * g.OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(top) & 15) == 0;
   }
   a.group_mask = p->use_dense ? ~0ull : p->dense_mask;
-  a.abl = 0;
-#ifdef ESCOIN_ABLATIONS
-  if (const char *e = getenv("ESCOIN_DENSE_ABL")) a.abl = atoi(e);
-#endif
+  a.abl = ESC_ABL_KNOB("DENSE_ABL");
   const int bm = g.Mg <= 64 ? 64 : 128;
   a.n_ptiles = (int)((P + kBN - 1) / kBN);
   a.n_mtiles = (g.Mg + bm - 1) / bm;
@@ -530,7 +542,7 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   // (same-call A/B on the chain, profiles/r04_dense_streamk.md: 784 tiles -13 %, 392 tiles -16 %, 1568 tiles -4..-5 %;
   // at 87.5 % occupancy -- 3136 tiles -- the fix-up costs more than the idle slots: +4..6 %).
   // ESCOIN_DENSE_STREAMK = 0 / 1 forces it off / on.
-  static const int sk_env = getenv("ESCOIN_DENSE_STREAMK") ? atoi(getenv("ESCOIN_DENSE_STREAMK")) : -1;
+  static const int sk_env = (int)ESC_KNOB("DENSE_STREAMK", -1);
   const long nk = (g.kdim + kBK - 1) / kBK;
   const long rounds = (tiles + slots - 1) / slots;
   const double occupancy = (double)tiles / (double)(rounds * slots);
@@ -542,7 +554,15 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   const long n_wg = streamk ? slots : std::min<long>(tiles, slots);
   a.sk_ws = nullptr;
   a.sk_flag = nullptr;
+  a.sk_fail = nullptr;
   if (streamk) {
+    if (!p->h_sk_fail) {
+      // one word of pinned, device-visible host memory per plan: a give-up in ANY launch stays there, and
+      // escoin_forward reads it without synchronising (escoin_capi.hip)
+      ESCOIN_HIP_TRY(hipHostMalloc((void **)&p->h_sk_fail, 64, hipHostMallocMapped));
+      *p->h_sk_fail = 0u;
+    }
+    ESCOIN_HIP_TRY(hipHostGetDevicePointer((void **)&a.sk_fail, p->h_sk_fail, 0));
     const size_t ws_bytes = (size_t)n_wg * 4 * 16 * 64 * 4 * sizeof(float);
     const size_t flag_bytes = ((size_t)(n_wg + 1) * 4 + 15) / 16 * 16;
     if (p->sk_ws_bytes < ws_bytes + flag_bytes) {

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "escoin_plan.h"
+#include "knobs.h"
 
 namespace escoin {
 
@@ -26,6 +27,21 @@ int fail(int code, const std::string &msg) {
 // crossover between the tiled sparse kernel and the dense kernel (profiles/r02_crossover.md).
 constexpr int kDefaultDenseThresholdPct = 50;
 constexpr int kGenericDenseThresholdPct = 4;
+
+// No exception may cross the C ABI (std::bad_alloc from the host vectors, std::system_error from a thread pool):
+// every entry point that allocates runs its body through this.
+template <typename F>
+static int guarded(F &&body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(ESCOIN_ENOMEM, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(ESCOIN_EINVAL, std::string("internal error: ") + e.what());
+  } catch (...) {
+    return fail(ESCOIN_EINVAL, "internal error");
+  }
+}
 
 static double ms_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -80,6 +96,8 @@ static void free_device(escoin_plan *p) {
   p->d_sk_ws = nullptr;
   p->sk_ws_bytes = 0;
   p->sk_flag_words = 0;
+  if (p->h_sk_fail) (void)hipHostFree(p->h_sk_fail);
+  p->h_sk_fail = nullptr;
   p->d_rowptr = p->d_taps = nullptr;
   p->d_vals = nullptr;
   p->device_bytes = 0;
@@ -173,7 +191,7 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
         return t_dense < t_sparse;
       };
       const bool use_model = p->dense_threshold_pct < 0 && fast_sparse && jit_available() &&
-                             !(getenv("ESCOIN_DENSE_MODEL") && atoi(getenv("ESCOIN_DENSE_MODEL")) == 0);
+                             (ESC_KNOB("DENSE_MODEL", 1) != 0);
       if (G <= 64) {
         for (int grp = 0; grp < G; ++grp) {
           const long n_g = (long)p->colidx[grp].size();
@@ -228,7 +246,7 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
     // stream kernel at every point (profiles/r04_crossover.md; the worst point, alex_conv2 @50 %, by 14 %).
     // ESCOIN_JIT_MAX_DENSITY_PCT restores a density cut for experiments; code beyond kMaxJitBytes
     // (sconv_tiled.hip) falls back to the stream kernel by itself.
-    static const int jit_max_density_pct = getenv("ESCOIN_JIT_MAX_DENSITY_PCT") ? atoi(getenv("ESCOIN_JIT_MAX_DENSITY_PCT")) : 100;
+    static const int jit_max_density_pct = (int)ESC_KNOB("JIT_MAX_DENSITY_PCT", 100);
     double dens_sparse = 0;
     long nz_sparse = 0;
     {
@@ -275,55 +293,42 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
   // Small launches.  The LDS-tiled kernels walk a tile block by block, every block a round trip to HBM, on as many
   // workgroups as the batch has tiles x columns: 11-19 us for one image of a GoogLeNet 1x1 layer; the generic kernel
   // puts a lane on every output pixel of the whole chip and needs 7-12 (profiles/r04_batch_sweep.md -- the reference's
-  // SCONV mode calls the layer image by image, conv_layer.cu:16-26).  Where the whole launch is under 64 MFLOP,
-  // KERNEL_AUTO therefore TIMES both kernels at WeightAlign -- zero-filled scratch blobs of the plan's batch, four
-  // launches each -- and keeps the generic kernel if it is more than a tenth faster.  ESCOIN_AUTO_TUNE=0: never.
-  static const bool auto_tune = !(getenv("ESCOIN_AUTO_TUNE") && atoi(getenv("ESCOIN_AUTO_TUNE")) == 0);
-  p->tuned_small = 0;
-  // (not for a plan whose tiling was asked for another batch, option "tiling_batch": its launches are not the ones
-  // the tiling is meant for)
-  if (auto_tune && p->kernel_choice == ESCOIN_KERNEL_AUTO && p->tiled.enabled && p->n_dense_groups == 0 &&
-      (p->tiling_batch <= 0 || p->tiling_batch == g.d.N)) {
-    long nnz_all = 0;
-    for (int grp = 0; grp < G; ++grp) nnz_all += (long)p->colidx[grp].size();
-    const double flops = 2.0 * g.d.N * g.OH * g.OW * (double)nnz_all;
-    if (flops < 64e6) {
-      const size_t in_bytes = sizeof(float) * (size_t)g.d.N * g.d.C * g.d.H * g.d.W;
-      const size_t out_bytes = sizeof(float) * (size_t)g.d.N * g.d.M * g.OH * g.OW;
-      float *scratch_in = nullptr, *scratch_out = nullptr;
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      float ms_fast = 0.f, ms_gen = 0.f;
-      bool ok = hipMalloc(&scratch_in, in_bytes) == hipSuccess && hipMalloc(&scratch_out, out_bytes) == hipSuccess &&
-                hipMemsetAsync(scratch_in, 0, in_bytes, stream) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
-                hipEventCreate(&e1) == hipSuccess;
-      p->aligned = true;       // (the launch functions check nothing else of the plan's state)
-      for (int which = 0; ok && which < 2; ++which) {
-        auto run = [&]() {
-          return which == 0 ? launch_tiled(p, scratch_in, nullptr, scratch_out, g.d.N, stream)
-                            : launch_generic(p, scratch_in, nullptr, scratch_out, g.d.N, stream);
-        };
-        ok = run() == ESCOIN_OK && hipEventRecord(e0, stream) == hipSuccess;
-        for (int k = 0; ok && k < 4; ++k) ok = run() == ESCOIN_OK;
-        ok = ok && hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-             hipEventElapsedTime(which == 0 ? &ms_fast : &ms_gen, e0, e1) == hipSuccess;
+  // SCONV mode calls the layer image by image, conv_layer.cu:16-26).  Round 4 TIMED both kernels here; a layer's bits
+  // then depended on the box's noise (two ranks could settle differently).  Now a RULE decides, from what WeightAlign
+  // knows -- the same weights, options and batch give the same kernel in every process:
+  //   pointwise layers only (the 3x3 / 5x5 layers keep generated code at every batch: the generic kernel needs
+  //   16-81 us where code needs 12-16), a launch of one round (tiles x columns <= CUs) under 64 MFLOP;
+  //   generic  ~ max(kGenFloor, kGenBase + kGenPerMflop x MFLOP)            us
+  //   code     ~ kCodeBase + max(walk, kCodePerBlock x blocks per tile)      us, walk = a wave's vector instructions
+  //              per tile at one instruction per 5.4 cycles
+  //   generic when it is more than a tenth faster by these estimates.
+  // Constants fitted to profiles/r05_small_launch_fit.md (tools/small_launch_fit.py: both kernels forced, 1-32 images
+  // of every distinct GoogLeNet 1x1 shape).
+  p->small_rule = 0;
+  if (p->kernel_choice == ESCOIN_KERNEL_AUTO && p->tiled.enabled && p->n_dense_groups == 0 &&
+      (p->tiling_batch <= 0 || p->tiling_batch == g.d.N) && g.d.KH == 1 && g.d.KW == 1) {
+    const double flops = 2.0 * g.d.N * g.OH * g.OW * (double)nnz;
+    const Tiling &t = p->tiled.tiling;
+    const long tiles = t.band_mode ? (long)g.d.N * t.bands : ((long)g.d.N + t.nseg - 1) / t.nseg;
+    const long wgs = tiles * t.n_ocblk * G;
+    if (flops < 64e6 && wgs <= tiled_device_cus()) {
+      constexpr double kGenFloor = 7.0, kGenBase = 4.5, kGenPerMflop = 0.55;
+      constexpr double kCodeBase = 6.5, kCodePerBlock = 0.85, kNsPerValu = 2.45;
+      const double dens = (double)nnz / (per_group * G);
+      // vector instructions of a wave per tile: two packed FMAs per nonzero and tile quad; its G channels' nonzeros
+      const double quads = (t.tpl == 1 || t.tr * t.nseg <= t.rows_per_slab) ? 1.0 : 2.0;
+      const double walk_us = (double)g.Cg * t.G * dens * 2.0 * quads * kNsPerValu * 1e-3;
+      const double t_code = kCodeBase + std::max(walk_us, kCodePerBlock * t.n_icb);
+      const double t_gen = std::max(kGenFloor, kGenBase + kGenPerMflop * flops * 1e-6);
+      p->small_rule = t_gen < 0.9 * t_code ? 2 : 1;
+      if (getenv("ESCOIN_VERBOSE"))
+        fprintf(stderr, "[escoin] small launch (%.1f MFLOP, %ld workgroups, %d blocks): code ~%.1f us, generic ~%.1f us -> %s\n",
+                flops * 1e-6, wgs, t.n_icb, t_code, t_gen, p->small_rule == 2 ? "generic" : "code");
+      if (p->small_rule == 2) {
+        const float d0 = p->tiled.density;
+        tiled_release(p);
+        p->tiled.density = d0;
       }
-      p->aligned = false;
-      if (e0) (void)hipEventDestroy(e0);
-      if (e1) (void)hipEventDestroy(e1);
-      if (scratch_in) (void)hipFree(scratch_in);
-      if (scratch_out) (void)hipFree(scratch_out);
-      if (ok) {
-        p->tuned_small = ms_gen < 0.9f * ms_fast ? 2 : 1;
-        if (getenv("ESCOIN_VERBOSE"))
-          fprintf(stderr, "[escoin] small launch (%.1f MFLOP): tiled %.1f us, generic %.1f us -> %s\n", flops * 1e-6,
-                  ms_fast * 250.0, ms_gen * 250.0, p->tuned_small == 2 ? "generic" : "tiled");
-        if (p->tuned_small == 2) {
-          const float dens = p->tiled.density;
-          tiled_release(p);
-          p->tiled.density = dens;
-        }
-      }
-      // (a failure of the measurement is not the layer's failure: the tiled kernel stays)
     }
   }
   p->kernel_name = p->tiled.enabled ? tiled_kernel_name(p) : generic_kernel_name(g.d.fuse_relu != 0);
@@ -362,19 +367,21 @@ long escoin_padded_len(const escoin_conv_desc *d) {
 }
 
 int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan) {
-  if (!plan) return fail(ESCOIN_EINVAL, "null plan pointer");
-  *plan = nullptr;
-  Geometry g;
-  int rc = validate(desc, &g);
-  if (rc != ESCOIN_OK) return rc;
-  escoin_plan *p = new (std::nothrow) escoin_plan();
-  if (!p) return fail(ESCOIN_ENOMEM, "out of host memory");
-  p->g = g;
-  p->rowptr.assign(g.d.group, std::vector<int>(g.Mg + 1, 0));
-  p->colidx.assign(g.d.group, std::vector<int>());
-  p->values.assign(g.d.group, std::vector<float>());
-  *plan = p;
-  return ESCOIN_OK;
+  return guarded([&]() -> int {
+    if (!plan) return fail(ESCOIN_EINVAL, "null plan pointer");
+    *plan = nullptr;
+    Geometry g;
+    int rc = validate(desc, &g);
+    if (rc != ESCOIN_OK) return rc;
+    escoin_plan *p = new (std::nothrow) escoin_plan();
+    if (!p) return fail(ESCOIN_ENOMEM, "out of host memory");
+    p->g = g;
+    p->rowptr.assign(g.d.group, std::vector<int>(g.Mg + 1, 0));
+    p->colidx.assign(g.d.group, std::vector<int>());
+    p->values.assign(g.d.group, std::vector<float>());
+    *plan = p;
+    return ESCOIN_OK;
+  });
 }
 
 int escoin_plan_destroy(escoin_plan *plan) {
@@ -385,106 +392,117 @@ int escoin_plan_destroy(escoin_plan *plan) {
 }
 
 int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
-  if (!p || !key) return fail(ESCOIN_EINVAL, "null argument");
-  if (p->aligned && strcmp(key, "conv_mode") != 0)
-    return fail(ESCOIN_ESTATE, "this option must be set before weight_align/set_csr");
-  if (!strcmp(key, "tiling_batch")) {
-    if (value < 0) return fail(ESCOIN_EINVAL, "tiling_batch must be >= 0");
-    p->tiling_batch = value;
-    return ESCOIN_OK;
-  }
-  if (!strcmp(key, "dense_threshold_pct")) {
-    if (value < -1 || value > 100) return fail(ESCOIN_EINVAL, "dense_threshold_pct must be in [-1, 100]");
-    p->dense_threshold_pct = value;
-    return ESCOIN_OK;
-  }
-  if (!strcmp(key, "stream_stores")) {
-    if (value < -1 || value > 1) return fail(ESCOIN_EINVAL, "stream_stores must be -1, 0 or 1");
-    p->stream_stores = value;
-    return ESCOIN_OK;
-  }
-  if (!strcmp(key, "kernel")) {
-    if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_JIT)
-      return fail(ESCOIN_EINVAL, "unknown kernel id");
-    p->kernel_choice = value;
-  } else if (!strcmp(key, "conv_mode")) {
-    if (value < ESCOIN_CONV_MODE_LOWERED_GEMM || value > ESCOIN_CONV_MODE_SCONV_PAR)
-      return fail(ESCOIN_EINVAL, "conv_mode must be one of Caffe::ConvMode's four values (0..3)");
-    const bool regroup = p->aligned && (value == ESCOIN_CONV_MODE_LOWERED_GEMM) !=
-                                           (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_GEMM);
-    p->conv_mode = value;
-    // to or from LOWERED_GEMM on an aligned plan: the dense / sparse device structures are rebuilt
-    // from the CSR the plan holds (the other three modes share theirs).  The plan is not aligned
-    // while that happens: if an allocation fails, the next forward reports ESCOIN_ESTATE instead of
-    // launching on freed pointers.  The rebuild must happen on the device the plan lives on.
-    if (regroup) {
-      int dev = -1;
-      if (hipGetDevice(&dev) != hipSuccess || dev != p->device)
-        return fail(ESCOIN_ESTATE, "conv_mode flip on an aligned plan: the current device is not the plan's device");
-      p->aligned = false;
-      return upload(p, nullptr);
+  return guarded([&]() -> int {
+    if (!p || !key) return fail(ESCOIN_EINVAL, "null argument");
+    if (p->aligned && strcmp(key, "conv_mode") != 0)
+      return fail(ESCOIN_ESTATE, "this option must be set before weight_align/set_csr");
+    if (!strcmp(key, "tiling_batch")) {
+      if (value < 0) return fail(ESCOIN_EINVAL, "tiling_batch must be >= 0");
+      p->tiling_batch = value;
+      return ESCOIN_OK;
     }
-  } else if (!strcmp(key, "dense_gate")) {
-    p->dense_gate = value != 0;
-  } else {
-    return fail(ESCOIN_EINVAL, std::string("unknown option: ") + key);
-  }
-  return ESCOIN_OK;
+    if (!strcmp(key, "max_launch_bytes")) {
+      if (value < 0) return fail(ESCOIN_EINVAL, "max_launch_bytes must be >= 0");
+      p->max_launch_bytes = value;
+      return ESCOIN_OK;
+    }
+    if (!strcmp(key, "dense_threshold_pct")) {
+      if (value < -1 || value > 100) return fail(ESCOIN_EINVAL, "dense_threshold_pct must be in [-1, 100]");
+      p->dense_threshold_pct = value;
+      return ESCOIN_OK;
+    }
+    if (!strcmp(key, "stream_stores")) {
+      if (value < -1 || value > 1) return fail(ESCOIN_EINVAL, "stream_stores must be -1, 0 or 1");
+      p->stream_stores = value;
+      return ESCOIN_OK;
+    }
+    if (!strcmp(key, "kernel")) {
+      if (value < ESCOIN_KERNEL_AUTO || value > ESCOIN_KERNEL_JIT)
+        return fail(ESCOIN_EINVAL, "unknown kernel id");
+      p->kernel_choice = value;
+    } else if (!strcmp(key, "conv_mode")) {
+      if (value < ESCOIN_CONV_MODE_LOWERED_GEMM || value > ESCOIN_CONV_MODE_SCONV_PAR)
+        return fail(ESCOIN_EINVAL, "conv_mode must be one of Caffe::ConvMode's four values (0..3)");
+      const bool regroup = p->aligned && (value == ESCOIN_CONV_MODE_LOWERED_GEMM) !=
+                                             (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_GEMM);
+      p->conv_mode = value;
+      // to or from LOWERED_GEMM on an aligned plan: the dense / sparse device structures are rebuilt
+      // from the CSR the plan holds (the other three modes share theirs).  The plan is not aligned
+      // while that happens: if an allocation fails, the next forward reports ESCOIN_ESTATE instead of
+      // launching on freed pointers.  The rebuild must happen on the device the plan lives on.
+      if (regroup) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != p->device)
+          return fail(ESCOIN_ESTATE, "conv_mode flip on an aligned plan: the current device is not the plan's device");
+        p->aligned = false;
+        return upload(p, nullptr);
+      }
+    } else if (!strcmp(key, "dense_gate")) {
+      p->dense_gate = value != 0;
+    } else {
+      return fail(ESCOIN_EINVAL, std::string("unknown option: ") + key);
+    }
+    return ESCOIN_OK;
+  });
 }
 
 int escoin_weight_align(escoin_plan *p, const float *dense_w, int w_on_device, void *stream) {
-  if (!p || !dense_w) return fail(ESCOIN_EINVAL, "null argument");
-  const auto t_start = std::chrono::steady_clock::now();
-  const Geometry &g = p->g;
-  const size_t count = (size_t)g.d.M * g.kdim;
-  std::vector<float> host;
-  const float *w = dense_w;
-  if (w_on_device) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-      return fail(ESCOIN_ENODEVICE, "no HIP device: cannot read device weights");
-    host.resize(count);
-    ESCOIN_HIP_TRY(hipMemcpyAsync(host.data(), dense_w, sizeof(float) * count,
-                                  hipMemcpyDeviceToHost, (hipStream_t)stream));
-    ESCOIN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    w = host.data();
-  }
-  // caffe_cpu_sparse_dense2csr, math_functions.cpp:92-105: row-major scan, keep != 0
-  const size_t weight_offset = (size_t)g.Mg * g.kdim;  // base_conv_layer.cpp:60
-  for (int grp = 0; grp < g.d.group; ++grp) {
-    std::vector<int> &rp = p->rowptr[grp];
-    std::vector<int> &ci = p->colidx[grp];
-    std::vector<float> &va = p->values[grp];
-    rp.assign(g.Mg + 1, 0);
-    ci.clear();
-    va.clear();
-    const float *A = w + weight_offset * grp;
-    for (int i = 0; i < g.Mg; ++i) {
-      for (int j = 0; j < g.kdim; ++j) {
-        const float v = A[(size_t)i * g.kdim + j];
-        if (v != 0) {
-          va.push_back(v);
-          ci.push_back(j);
-        }
-      }
-      rp[i + 1] = (int)ci.size();
+  return guarded([&]() -> int {
+    if (!p || !dense_w) return fail(ESCOIN_EINVAL, "null argument");
+    const auto t_start = std::chrono::steady_clock::now();
+    const Geometry &g = p->g;
+    const size_t count = (size_t)g.d.M * g.kdim;
+    std::vector<float> host;
+    const float *w = dense_w;
+    if (w_on_device) {
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(ESCOIN_ENODEVICE, "no HIP device: cannot read device weights");
+      host.resize(count);
+      ESCOIN_HIP_TRY(hipMemcpyAsync(host.data(), dense_w, sizeof(float) * count,
+                                    hipMemcpyDeviceToHost, (hipStream_t)stream));
+      ESCOIN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      w = host.data();
     }
-  }
-  p->aligned = false;
-  const int rc = upload(p, (hipStream_t)stream);
-  p->align_ms = ms_since(t_start);
-  return rc;
+    // caffe_cpu_sparse_dense2csr, math_functions.cpp:92-105: row-major scan, keep != 0
+    const size_t weight_offset = (size_t)g.Mg * g.kdim;  // base_conv_layer.cpp:60
+    for (int grp = 0; grp < g.d.group; ++grp) {
+      std::vector<int> &rp = p->rowptr[grp];
+      std::vector<int> &ci = p->colidx[grp];
+      std::vector<float> &va = p->values[grp];
+      rp.assign(g.Mg + 1, 0);
+      ci.clear();
+      va.clear();
+      const float *A = w + weight_offset * grp;
+      for (int i = 0; i < g.Mg; ++i) {
+        for (int j = 0; j < g.kdim; ++j) {
+          const float v = A[(size_t)i * g.kdim + j];
+          if (v != 0) {
+            va.push_back(v);
+            ci.push_back(j);
+          }
+        }
+        rp[i + 1] = (int)ci.size();
+      }
+    }
+    p->aligned = false;
+    const int rc = upload(p, (hipStream_t)stream);
+    p->align_ms = ms_since(t_start);
+    return rc;
+  });
 }
 
 int escoin_plan_set_csr(escoin_plan *p, const int *rowptr, const int *colidx, const float *values,
                         const int *nnz_per_group, void *stream) {
-  const auto t_start = std::chrono::steady_clock::now();
-  const int rc = set_csr_host(p, rowptr, colidx, values, nnz_per_group);
-  if (rc != ESCOIN_OK) return rc;
-  p->aligned = false;
-  const int rc2 = upload(p, (hipStream_t)stream);
-  p->align_ms = ms_since(t_start);
-  return rc2;
+  return guarded([&]() -> int {
+    const auto t_start = std::chrono::steady_clock::now();
+    const int rc = set_csr_host(p, rowptr, colidx, values, nnz_per_group);
+    if (rc != ESCOIN_OK) return rc;
+    p->aligned = false;
+    const int rc2 = upload(p, (hipStream_t)stream);
+    p->align_ms = ms_since(t_start);
+    return rc2;
+  });
 }
 
 }  // extern "C"
@@ -535,68 +553,75 @@ struct AlignedHdr {
 }  // namespace
 
 int escoin_plan_export_aligned(const escoin_plan *p, void *buf, size_t capacity, size_t *bytes) {
-  if (!p || !bytes) return fail(ESCOIN_EINVAL, "null argument");
-  if (!p->aligned) return fail(ESCOIN_ESTATE, "export_aligned before weight_align / set_csr");
-  const Geometry &g = p->g;
-  std::vector<char> jit;
-  const int rc = tiled_export(p, &jit);
-  if (rc != ESCOIN_OK) return rc;
-  uint64_t nnz = 0;
-  for (const auto &c : p->colidx) nnz += c.size();
-  const size_t need = sizeof(AlignedHdr) + sizeof(escoin_conv_desc) + 4 * (size_t)g.d.group +
-                      4 * (size_t)g.d.group * (g.Mg + 1) + 8 * (size_t)nnz + jit.size();
-  *bytes = need;
-  if (!buf) return ESCOIN_OK;                       // size query
-  if (capacity < need) return fail(ESCOIN_EINVAL, "export_aligned: buffer too small");
-  char *q = static_cast<char *>(buf);
-  AlignedHdr h{kAlignedMagic, 1u, (uint64_t)need, nnz, (uint64_t)jit.size()};
-  memcpy(q, &h, sizeof(h)); q += sizeof(h);
-  memcpy(q, &g.d, sizeof(g.d)); q += sizeof(g.d);
-  for (int grp = 0; grp < g.d.group; ++grp) { const int n = (int)p->colidx[grp].size(); memcpy(q, &n, 4); q += 4; }
-  for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->rowptr[grp].data(), 4 * (size_t)(g.Mg + 1)); q += 4 * (size_t)(g.Mg + 1); }
-  for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->colidx[grp].data(), 4 * p->colidx[grp].size()); q += 4 * p->colidx[grp].size(); }
-  for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->values[grp].data(), 4 * p->values[grp].size()); q += 4 * p->values[grp].size(); }
-  if (!jit.empty()) memcpy(q, jit.data(), jit.size());
-  return ESCOIN_OK;
+  return guarded([&]() -> int {
+    if (!p || !bytes) return fail(ESCOIN_EINVAL, "null argument");
+    if (!p->aligned) return fail(ESCOIN_ESTATE, "export_aligned before weight_align / set_csr");
+    const Geometry &g = p->g;
+    std::vector<char> jit;
+    const int rc = tiled_export(p, &jit);
+    if (rc != ESCOIN_OK) return rc;
+    uint64_t nnz = 0;
+    for (const auto &c : p->colidx) nnz += c.size();
+    const size_t need = sizeof(AlignedHdr) + sizeof(escoin_conv_desc) + 4 * (size_t)g.d.group +
+                        4 * (size_t)g.d.group * (g.Mg + 1) + 8 * (size_t)nnz + jit.size();
+    *bytes = need;
+    if (!buf) return ESCOIN_OK;                       // size query
+    if (capacity < need) return fail(ESCOIN_EINVAL, "export_aligned: buffer too small");
+    char *q = static_cast<char *>(buf);
+    AlignedHdr h{kAlignedMagic, 1u, (uint64_t)need, nnz, (uint64_t)jit.size()};
+    memcpy(q, &h, sizeof(h)); q += sizeof(h);
+    memcpy(q, &g.d, sizeof(g.d)); q += sizeof(g.d);
+    for (int grp = 0; grp < g.d.group; ++grp) { const int n = (int)p->colidx[grp].size(); memcpy(q, &n, 4); q += 4; }
+    for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->rowptr[grp].data(), 4 * (size_t)(g.Mg + 1)); q += 4 * (size_t)(g.Mg + 1); }
+    for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->colidx[grp].data(), 4 * p->colidx[grp].size()); q += 4 * p->colidx[grp].size(); }
+    for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->values[grp].data(), 4 * p->values[grp].size()); q += 4 * p->values[grp].size(); }
+    if (!jit.empty()) memcpy(q, jit.data(), jit.size());
+    return ESCOIN_OK;
+  });
 }
 
 int escoin_plan_import_aligned(escoin_plan *p, const void *buf, size_t bytes, void *stream) {
-  if (!p || !buf) return fail(ESCOIN_EINVAL, "null argument");
-  const auto t_start = std::chrono::steady_clock::now();
-  const Geometry &g = p->g;
-  AlignedHdr h;
-  if (bytes < sizeof(h) + sizeof(escoin_conv_desc)) return fail(ESCOIN_EINVAL, "import_aligned: truncated blob");
-  const char *q = static_cast<const char *>(buf);
-  memcpy(&h, q, sizeof(h)); q += sizeof(h);
-  if (h.magic != kAlignedMagic || h.version != 1u || h.total_bytes != bytes)
-    return fail(ESCOIN_EINVAL, "import_aligned: not an aligned-form blob of this library");
-  escoin_conv_desc d;
-  memcpy(&d, q, sizeof(d)); q += sizeof(d);
-  // the weights' own geometry must match; batch, bias and ReLU are the importing plan's business
-  if (d.C != g.d.C || d.M != g.d.M || d.KH != g.d.KH || d.KW != g.d.KW || d.group != g.d.group)
-    return fail(ESCOIN_EINVAL, "import_aligned: the blob was exported for other weights (C / M / kernel / group differ)");
-  const size_t csr_bytes = 4 * (size_t)g.d.group + 4 * (size_t)g.d.group * (g.Mg + 1) + 8 * (size_t)h.nnz;
-  if (sizeof(h) + sizeof(d) + csr_bytes + h.jit_bytes != bytes) return fail(ESCOIN_EINVAL, "import_aligned: section sizes do not add up");
-  std::vector<int> ng(g.d.group), rp((size_t)g.d.group * (g.Mg + 1)), ci((size_t)h.nnz);
-  std::vector<float> va((size_t)h.nnz);
-  memcpy(ng.data(), q, 4 * ng.size()); q += 4 * ng.size();
-  memcpy(rp.data(), q, 4 * rp.size()); q += 4 * rp.size();
-  memcpy(ci.data(), q, 4 * ci.size()); q += 4 * ci.size();
-  memcpy(va.data(), q, 4 * va.size()); q += 4 * va.size();
-  uint64_t sum = 0;
-  for (int n : ng) sum += (uint64_t)std::max(0, n);
-  if (sum != h.nnz) return fail(ESCOIN_EINVAL, "import_aligned: nnz_per_group does not match the blob's nnz");
-  const int rc = set_csr_host(p, rp.data(), ci.data(), va.data(), ng.data());
-  if (rc != ESCOIN_OK) return rc;
-  p->aligned = false;
-  // the code section only counts for the geometry it was generated for (the LDS offsets in the code
-  // are this H x W's) and for the same epilogue flags
-  const bool same_geom = d.H == g.d.H && d.W == g.d.W && d.pad_h == g.d.pad_h && d.pad_w == g.d.pad_w &&
-                         d.stride_h == g.d.stride_h && d.stride_w == g.d.stride_w && d.dil_h == g.d.dil_h &&
-                         d.dil_w == g.d.dil_w && d.N == g.d.N;
-  const int rc2 = upload(p, (hipStream_t)stream, same_geom && h.jit_bytes ? q : nullptr, same_geom ? (size_t)h.jit_bytes : 0);
-  p->align_ms = ms_since(t_start);
-  return rc2;
+  return guarded([&]() -> int {
+    if (!p || !buf) return fail(ESCOIN_EINVAL, "null argument");
+    const auto t_start = std::chrono::steady_clock::now();
+    const Geometry &g = p->g;
+    AlignedHdr h;
+    if (bytes < sizeof(h) + sizeof(escoin_conv_desc)) return fail(ESCOIN_EINVAL, "import_aligned: truncated blob");
+    const char *q = static_cast<const char *>(buf);
+    memcpy(&h, q, sizeof(h)); q += sizeof(h);
+    if (h.magic != kAlignedMagic || h.version != 1u || h.total_bytes != bytes)
+      return fail(ESCOIN_EINVAL, "import_aligned: not an aligned-form blob of this library");
+    escoin_conv_desc d;
+    memcpy(&d, q, sizeof(d)); q += sizeof(d);
+    // the weights' own geometry must match; batch, bias and ReLU are the importing plan's business
+    if (d.C != g.d.C || d.M != g.d.M || d.KH != g.d.KH || d.KW != g.d.KW || d.group != g.d.group)
+      return fail(ESCOIN_EINVAL, "import_aligned: the blob was exported for other weights (C / M / kernel / group differ)");
+    // (bounded before it sizes anything: a layer has at most group * Mg * kdim weights)
+    if (h.nnz > (uint64_t)g.d.group * (uint64_t)g.Mg * (uint64_t)g.kdim || h.jit_bytes > bytes)
+      return fail(ESCOIN_EINVAL, "import_aligned: nnz or code section larger than the layer / the blob");
+    const size_t csr_bytes = 4 * (size_t)g.d.group + 4 * (size_t)g.d.group * (g.Mg + 1) + 8 * (size_t)h.nnz;
+    if (sizeof(h) + sizeof(d) + csr_bytes + h.jit_bytes != bytes) return fail(ESCOIN_EINVAL, "import_aligned: section sizes do not add up");
+    std::vector<int> ng(g.d.group), rp((size_t)g.d.group * (g.Mg + 1)), ci((size_t)h.nnz);
+    std::vector<float> va((size_t)h.nnz);
+    memcpy(ng.data(), q, 4 * ng.size()); q += 4 * ng.size();
+    memcpy(rp.data(), q, 4 * rp.size()); q += 4 * rp.size();
+    memcpy(ci.data(), q, 4 * ci.size()); q += 4 * ci.size();
+    memcpy(va.data(), q, 4 * va.size()); q += 4 * va.size();
+    uint64_t sum = 0;
+    for (int n : ng) sum += (uint64_t)std::max(0, n);
+    if (sum != h.nnz) return fail(ESCOIN_EINVAL, "import_aligned: nnz_per_group does not match the blob's nnz");
+    const int rc = set_csr_host(p, rp.data(), ci.data(), va.data(), ng.data());
+    if (rc != ESCOIN_OK) return rc;
+    p->aligned = false;
+    // the code section only counts for the geometry it was generated for (the LDS offsets in the code
+    // are this H x W's) and for the same epilogue flags
+    const bool same_geom = d.H == g.d.H && d.W == g.d.W && d.pad_h == g.d.pad_h && d.pad_w == g.d.pad_w &&
+                           d.stride_h == g.d.stride_h && d.stride_w == g.d.stride_w && d.dil_h == g.d.dil_h &&
+                           d.dil_w == g.d.dil_w && d.N == g.d.N;
+    const int rc2 = upload(p, (hipStream_t)stream, same_geom && h.jit_bytes ? q : nullptr, same_geom ? (size_t)h.jit_bytes : 0);
+    p->align_ms = ms_since(t_start);
+    return rc2;
+  });
 }
 
 long escoin_plan_stat(const escoin_plan *p, const char *key) {
@@ -605,15 +630,20 @@ long escoin_plan_stat(const escoin_plan *p, const char *key) {
   if (!strcmp(key, "code_bytes")) return (long)(p->tiled.enabled && p->tiled.jit ? p->jit_module.code_bytes : 0);
   if (!strcmp(key, "device_bytes")) return (long)p->device_bytes;
   if (!strcmp(key, "import_fast")) return p->import_fast ? 1 : 0;
-  if (!strcmp(key, "tuned_small")) return p->tuned_small;
+  if (!strcmp(key, "small_launch_rule")) return p->small_rule;
   if (!strcmp(key, "jit_rows")) return p->tiled.jit ? p->tiled.jit_rows : 0;
   if (!strcmp(key, "jit_records")) return p->tiled.jit ? p->tiled.jit_records : 0;
+  // balance of the channel deal, x 1000 (1000 = every wave of every block costs the same; generated-code plans
+  // built from weights -- 0 for an imported code object, which does not carry the figure)
+  if (!strcmp(key, "deal_slowest_over_mean_x1000")) return p->tiled.jit ? (long)(p->tiled.deal_slowest_over_mean * 1000.f + 0.5f) : 0;
+  if (!strcmp(key, "deal_worst_block_x1000")) return p->tiled.jit ? (long)(p->tiled.deal_worst_block * 1000.f + 0.5f) : 0;
   if (!strcmp(key, "lds_bytes")) return p->tiled.enabled ? (long)p->tiled.lds_bytes : 0;
   if (!strcmp(key, "workgroup_columns")) return p->tiled.enabled ? p->tiled.tiling.n_ocblk : 0;
   if (!strcmp(key, "streamk_gave_up")) {
     // dense kernel, stream-K launches: 1 if a workgroup's bounded wait for another one's partial sums ran out in
     // the last launch (its results are then wrong); synchronises with the device.  0 for plans that never split K.
     if (!p->d_sk_ws || p->sk_flag_words < 1) return 0;
+    if (p->h_sk_fail && *(volatile unsigned *)p->h_sk_fail != 0u) return 1;      // (sticky: any launch since WeightAlign)
     unsigned v = 0;
     if (hipMemcpy(&v, static_cast<const unsigned *>(p->d_sk_ws) + (p->sk_flag_words - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
       return fail(ESCOIN_EHIP, "streamk_gave_up: device read failed");
@@ -640,24 +670,26 @@ long escoin_plan_nnz(const escoin_plan *p, int group) {
 
 int escoin_plan_get_csr(const escoin_plan *p, int *rowptr, int *colidx, float *values,
                         int stretched) {
-  if (!p || !rowptr) return fail(ESCOIN_EINVAL, "null argument");
-  const Geometry &g = p->g;
-  long base = 0;
-  for (int grp = 0; grp < g.d.group; ++grp) {
-    memcpy(rowptr + (size_t)grp * (g.Mg + 1), p->rowptr[grp].data(), sizeof(int) * (g.Mg + 1));
-    const long n_g = (long)p->colidx[grp].size();
-    for (long j = 0; j < n_g; ++j) {
-      int col = p->colidx[grp][j];
-      if (stretched) {  // base_conv_layer.cpp:99-105
-        const int kc = col % g.d.KW, kr = (col / g.d.KW) % g.d.KH, ic = col / (g.d.KW * g.d.KH);
-        col = (ic * (g.d.H + g.d.pad_h) + kr) * (g.d.W + g.d.pad_w) + kc;
+  return guarded([&]() -> int {
+    if (!p || !rowptr) return fail(ESCOIN_EINVAL, "null argument");
+    const Geometry &g = p->g;
+    long base = 0;
+    for (int grp = 0; grp < g.d.group; ++grp) {
+      memcpy(rowptr + (size_t)grp * (g.Mg + 1), p->rowptr[grp].data(), sizeof(int) * (g.Mg + 1));
+      const long n_g = (long)p->colidx[grp].size();
+      for (long j = 0; j < n_g; ++j) {
+        int col = p->colidx[grp][j];
+        if (stretched) {  // base_conv_layer.cpp:99-105
+          const int kc = col % g.d.KW, kr = (col / g.d.KW) % g.d.KH, ic = col / (g.d.KW * g.d.KH);
+          col = (ic * (g.d.H + g.d.pad_h) + kr) * (g.d.W + g.d.pad_w) + kc;
+        }
+        if (colidx) colidx[base + j] = col;
+        if (values) values[base + j] = p->values[grp][j];
       }
-      if (colidx) colidx[base + j] = col;
-      if (values) values[base + j] = p->values[grp][j];
+      base += n_g;
     }
-    base += n_g;
-  }
-  return ESCOIN_OK;
+    return ESCOIN_OK;
+  });
 }
 
 size_t escoin_plan_workspace_bytes(const escoin_plan *p) { return p ? p->device_bytes : 0; }
@@ -675,26 +707,34 @@ const char *escoin_plan_tiling_info(const escoin_plan *p) {
 
 int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_dev, float *top_dev,
                    int n_images, void *stream) {
-  if (!p || !bottom_dev || !top_dev) return fail(ESCOIN_EINVAL, "null argument");
-  if (!p->aligned) return fail(ESCOIN_ESTATE, "forward called before weight_align / set_csr");
-  if (n_images < 0 || n_images > p->g.d.N)
-    return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
-  if (n_images == 0) return ESCOIN_OK;
-  {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev != p->device)
-      return fail(ESCOIN_ESTATE, "forward: the current device is not the device the plan was aligned on");
-  }
-  hipStream_t s = (hipStream_t)stream;
-  // LOWERED_SPARSE lowers every group, whatever AUTO decided for the direct path
-  if (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && p->kernel_choice != ESCOIN_KERNEL_DENSE)
-    return launch_lowered(p, bottom_dev, bias_dev, top_dev, n_images, s);
-  if (p->n_dense_groups > 0) {
-    const int rc = launch_dense(p, bottom_dev, bias_dev, top_dev, n_images, s);
-    if (rc != ESCOIN_OK || p->use_dense) return rc;
-  }
-  if (p->tiled.enabled) return launch_tiled(p, bottom_dev, bias_dev, top_dev, n_images, s);
-  return launch_generic(p, bottom_dev, bias_dev, top_dev, n_images, s);
+  return guarded([&]() -> int {
+    if (!p || !bottom_dev || !top_dev) return fail(ESCOIN_EINVAL, "null argument");
+    if (!p->aligned) return fail(ESCOIN_ESTATE, "forward called before weight_align / set_csr");
+    if (n_images < 0 || n_images > p->g.d.N)
+      return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
+    if (n_images == 0) return ESCOIN_OK;
+    {
+      int dev = -1;
+      if (hipGetDevice(&dev) != hipSuccess || dev != p->device)
+        return fail(ESCOIN_ESTATE, "forward: the current device is not the device the plan was aligned on");
+    }
+    // dense kernel, stream-K: a fix-up wait that ran out in an EARLIER launch of this plan left wrong results in that
+    // launch's top blob.  The word lives in pinned host memory (no synchronisation here) and stays set until the
+    // next WeightAlign: the caller hears about it at the next call at the latest (dense_mfma.hip).
+    if (p->h_sk_fail && *(volatile unsigned *)p->h_sk_fail != 0u)
+      return fail(ESCOIN_EHIP, "dense kernel (stream-K): a workgroup gave up waiting for another one's partial sums in an "
+                               "earlier launch of this plan; that launch's results are wrong");
+    hipStream_t s = (hipStream_t)stream;
+    // LOWERED_SPARSE lowers every group, whatever AUTO decided for the direct path
+    if (p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE && p->kernel_choice != ESCOIN_KERNEL_DENSE)
+      return launch_lowered(p, bottom_dev, bias_dev, top_dev, n_images, s);
+    if (p->n_dense_groups > 0) {
+      const int rc = launch_dense(p, bottom_dev, bias_dev, top_dev, n_images, s);
+      if (rc != ESCOIN_OK || p->use_dense) return rc;
+    }
+    if (p->tiled.enabled) return launch_tiled(p, bottom_dev, bias_dev, top_dev, n_images, s);
+    return launch_generic(p, bottom_dev, bias_dev, top_dev, n_images, s);
+  });
 }
 
 int escoin_gpu_sparse_csrmm(int M, int N, int K, int nnz, float alpha, const float *values,

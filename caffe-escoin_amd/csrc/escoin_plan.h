@@ -60,6 +60,7 @@ struct TiledConfig {
   int dma_period = 0;        // quads covered by the quad table (lcm of the plane size and 64)
   int jit_pref = 0;          // code touches at the start of every unit
   bool jit_chain = false;    // a tile's units run as one chain (jit_codegen.h ChainPlan)
+  float deal_slowest_over_mean = 1.f, deal_worst_block = 1.f;   // balance of the channel deal (jit_codegen.h Program)
   std::string info;          // escoin_plan_tiling_info
 };
 
@@ -70,6 +71,7 @@ struct escoin_plan {
   int kernel_choice = ESCOIN_KERNEL_AUTO;
   int conv_mode = ESCOIN_CONV_MODE_SCONV_PAR;
   int dense_gate = 0;
+  long max_launch_bytes = 0;   // option "max_launch_bytes": bottom-blob bytes one tiled launch may cover (0: the 4 GiB descriptor range)
   int tiling_batch = 0;   // option "tiling_batch": choose the tiled kernel's tiling as for this batch (0: desc.N)
   bool aligned = false;
   int device = -1;
@@ -99,7 +101,7 @@ struct escoin_plan {
   std::vector<uint32_t> h_unit_off, h_chan;
   double align_ms = 0.0;          // wall time of the last weight_align / set_csr / import_aligned
   bool import_fast = false;       // the last import_aligned loaded a persisted code object as it was
-  int tuned_small = 0;             // KERNEL_AUTO timed the tiled and the generic kernel on a small launch: 1 kept tiled, 2 took generic
+  int small_rule = 0;              // KERNEL_AUTO's small-launch rule applied to this plan: 0 not considered, 1 kept generated code, 2 took the generic kernel
 
   // dense fallback (fp32 MFMA implicit GEMM), chosen per conv group: bit g of dense_mask = group g
   // goes to the MFMA kernel, bit g of sparse_mask = to the sparse kernels (layers with more than 64
@@ -117,6 +119,7 @@ struct escoin_plan {
   mutable void *d_sk_ws = nullptr;
   mutable size_t sk_ws_bytes = 0;
   mutable int sk_flag_words = 0;
+  mutable unsigned *h_sk_fail = nullptr;   // pinned host word the kernel sets when a fix-up wait gave up (sticky until the next WeightAlign)
 
   // LOWERED_SPARSE comparator (sconv_lowered.hip): column buffer, grown on demand
   float *d_col = nullptr;
@@ -135,6 +138,7 @@ const char *generic_kernel_name(bool relu);
 
 // sconv_tiled.hip
 bool tiled_supported(const Geometry &g);
+int tiled_device_cus();             // compute units of the current device
 int tiled_build(escoin_plan *p, hipStream_t stream, bool jit);  // fills p->tiled, uploads streams / loads generated code
 void tiled_release(escoin_plan *p);   // frees what tiled_build put on the device (and its share of device_bytes)
 // The fast half of escoin_plan_import_aligned: a generated-code plan restored from what

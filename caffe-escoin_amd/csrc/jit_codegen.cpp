@@ -1,10 +1,13 @@
 // jit_codegen.cpp -- see jit_codegen.h
 #include "jit_codegen.h"
 
+#include "knobs.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
 #include <thread>
 
 namespace escoin {
@@ -28,15 +31,16 @@ int dma_period(int qpc, int max_period, double slack, int *padded) {
 
 Options options_from_env() {
   Options o;
-  if (const char *e = getenv("ESCOIN_JIT_DEPTH")) o.depth = std::max(1, std::min(2, atoi(e)));
-  if (const char *e = getenv("ESCOIN_JIT_DEPTH1")) o.depth_one_tile = std::max(1, std::min(13, atoi(e)));
-  if (const char *e = getenv("ESCOIN_JIT_HI_SETS")) o.hi_sets = std::max(0, std::min(24, atoi(e)));
-  if (const char *e = getenv("ESCOIN_JIT_HOIST")) o.hoist_weight = atoi(e) != 0;
-  if (const char *e = getenv("ESCOIN_JIT_PRIO_ROWS")) o.prio_rows = std::max(0, atoi(e));
-  if (const char *e = getenv("ESCOIN_JIT_PRIO_WAVES")) o.prio_waves = std::max(0, atoi(e));
-  if (const char *e = getenv("ESCOIN_JIT_ABL")) o.ablate = atoi(e);
-  if (const char *e = getenv("ESCOIN_JIT_PREFETCH")) o.prefetch = atoi(e) != 0;
-  if (const char *e = getenv("ESCOIN_JIT_ONE_TILE")) o.one_tile = atoi(e) != 0 ? 0 : -1;
+  // (all compile-time constants in the product build: knobs.h)
+  o.depth = std::max(1, std::min(2, (int)ESC_KNOB("JIT_DEPTH", o.depth)));
+  o.depth_one_tile = std::max(1, std::min(13, (int)ESC_KNOB("JIT_DEPTH1", o.depth_one_tile)));
+  o.hi_sets = std::max(0, std::min(24, (int)ESC_KNOB("JIT_HI_SETS", o.hi_sets)));
+  o.hoist_weight = ESC_KNOB("JIT_HOIST", o.hoist_weight) != 0;
+  o.prio_rows = std::max(0, (int)ESC_KNOB("JIT_PRIO_ROWS", o.prio_rows));
+  o.prio_waves = std::max(0, (int)ESC_KNOB("JIT_PRIO_WAVES", o.prio_waves));
+  o.ablate = ESC_ABL_KNOB("JIT_ABL");
+  o.prefetch = ESC_KNOB("JIT_PREFETCH", o.prefetch) != 0;
+  if (ESC_KNOB_SET("JIT_ONE_TILE")) o.one_tile = ESC_KNOB("JIT_ONE_TILE", 1) != 0 ? 0 : -1;
   return o;
 }
 
@@ -262,6 +266,7 @@ struct ChainOut {
   long n_rows = 0, n_records = 0, n_dma = 0;
   bool overflow = false;
   size_t max_unit = 0;
+  std::vector<double> blk_cost;     // [n_icb] instructions of the walk per block: 3 per nonempty row + 5 per nonzero
 };
 
 void emit_chain(const ConvGeom &g, const Tiling &t, const std::vector<int> &rowptr, const std::vector<int> &colidx,
@@ -303,6 +308,11 @@ void emit_chain(const ConvGeom &g, const Tiling &t, const std::vector<int> &rowp
       live.push_back(std::move(row));
     }
     p.n_rows += (long)live.size();
+    {
+      long recs = 0;
+      for (const Row &r : live) recs += (long)r.recs.size();
+      p.blk_cost.push_back(3.0 * (double)live.size() + 5.0 * (double)recs);
+    }
     // this wave's pieces of the block staged while this unit runs: block blk + ahead of this tile
     // or, past its last block, of the workgroup's next tile
     pieces.clear();
@@ -365,12 +375,20 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
   if (n_thr <= 1) {
     for (size_t ci = 0; ci < n_chains; ++ci) run(ci);
   } else {
+    // (the calling thread works too; a thread the system refuses to create is simply one worker fewer)
     std::vector<std::thread> pool;
     std::atomic<size_t> next{0};
-    for (size_t th = 0; th < n_thr; ++th)
-      pool.emplace_back([&]() {
-        for (size_t i = next.fetch_add(1); i < n_chains; i = next.fetch_add(1)) run(i);
-      });
+    auto worker = [&]() {
+      for (size_t i = next.fetch_add(1); i < n_chains; i = next.fetch_add(1)) run(i);
+    };
+    for (size_t th = 1; th < n_thr; ++th) {
+      try {
+        pool.emplace_back(worker);
+      } catch (const std::system_error &) {
+        break;
+      }
+    }
+    worker();
     for (auto &th : pool) th.join();
   }
   size_t total = 0;
@@ -385,6 +403,31 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
     p.n_rows += c.n_rows; p.n_records += c.n_records; p.n_dma += c.n_dma;
     p.overflow = p.overflow || c.overflow;
     *max_unit_bytes = std::max(*max_unit_bytes, c.max_unit);
+  }
+  // How well the channel deal balanced the waves: the waves of a workgroup column meet at a barrier after every
+  // block, so a block costs its SLOWEST wave.  sum over (conv group, column, block) of the slowest wave's
+  // instructions / sum of the mean wave's = what the barriers make a launch wait for (1.0 = perfectly even);
+  // the worst single block is reported too (blocks under 64 instructions per wave are noise and left out of it).
+  {
+    double sum_max = 0, sum_mean = 0, worst = 1.0;
+    const int ow = std::max(1, t.oc_waves);
+    for (int cg = 0; cg < g.group; ++cg)
+      for (int col = 0; col * ow < t.n_ocg; ++col)
+        for (int blk = 0; blk < t.n_icb; ++blk) {
+          double mx = 0, tot = 0;
+          int n = 0;
+          for (int w = 0; w < ow && col * ow + w < t.n_ocg; ++w, ++n) {
+            const double c = outs[(size_t)cg * t.n_ocg + col * ow + w].blk_cost[blk];
+            mx = std::max(mx, c);
+            tot += c;
+          }
+          if (n == 0 || tot <= 0) continue;
+          sum_max += mx;
+          sum_mean += tot / n;
+          if (tot / n >= 64.0) worst = std::max(worst, mx / (tot / n));
+        }
+    p.deal_slowest_over_mean = sum_mean > 0 ? sum_max / sum_mean : 1.0;
+    p.deal_worst_block = worst;
   }
   // instruction prefetch and the code touches run past the last unit: keep them inside the blob
   for (int i = 0; i < 64 + n_pref * 1024; ++i) enc_nop(p.code);

@@ -223,6 +223,8 @@ struct Program {
   int n_pref = 0;                   // code touches (plain loads) at the start of every unit
   bool overflow = false;            // an LDS offset does not fit the instruction's 16-bit field
   bool chained = false;             // the units of an oc-group run as one chain per tile (ChainPlan)
+  // balance of the channel deal (build_pass): barrier-weighted slowest / mean wave over all blocks, and the worst block
+  double deal_slowest_over_mean = 1.0, deal_worst_block = 1.0;
 };
 
 Program build_program(const ConvGeom &g, const Tiling &t, const std::vector<std::vector<int>> &rowptr,

@@ -12,6 +12,7 @@
 #include <string>
 
 #include "escoin_plan.h"
+#include "knobs.h"
 
 namespace escoin {
 
@@ -151,7 +152,7 @@ done:
 }  // namespace
 
 bool jit_available() {
-  static const bool on = !(getenv("ESCOIN_JIT") && atoi(getenv("ESCOIN_JIT")) == 0);
+  static const bool on = (ESC_KNOB("JIT", 1) != 0);
   return on;
 }
 
@@ -166,7 +167,29 @@ static std::string tmp_dir() {
 }
 
 int jit_load_elf(const std::vector<char> &elf, size_t code_bytes, JitModule *out, hipStream_t stream) {
-  if (elf.size() < 64 || std::memcmp(elf.data(), "\177ELF", 4) != 0) return fail(ESCOIN_EINVAL, "jit: not a code object");
+  if (elf.size() < sizeof(Elf64_Ehdr) || std::memcmp(elf.data(), "\177ELF", 4) != 0) return fail(ESCOIN_EINVAL, "jit: not a code object");
+  {
+    // hipModuleLoadData takes no length: the header's tables must lie inside the bytes we hold (a truncated or
+    // foreign blob reaches here through escoin_plan_import_aligned)
+    Elf64_Ehdr eh;
+    std::memcpy(&eh, elf.data(), sizeof(eh));
+    const uint64_t n = elf.size();
+    if (eh.e_ident[EI_CLASS] != ELFCLASS64 || eh.e_machine != 224 /* EM_AMDGPU */ || eh.e_phentsize != sizeof(Elf64_Phdr) ||
+        eh.e_shentsize != sizeof(Elf64_Shdr) || eh.e_phoff > n || (uint64_t)eh.e_phnum * sizeof(Elf64_Phdr) > n - eh.e_phoff ||
+        eh.e_shoff > n || (uint64_t)eh.e_shnum * sizeof(Elf64_Shdr) > n - eh.e_shoff || code_bytes > n)
+      return fail(ESCOIN_EINVAL, "jit: code object header out of bounds");
+    for (unsigned i = 0; i < eh.e_phnum; ++i) {
+      Elf64_Phdr ph;
+      std::memcpy(&ph, elf.data() + eh.e_phoff + (size_t)i * sizeof(ph), sizeof(ph));
+      if (ph.p_offset > n || ph.p_filesz > n - ph.p_offset) return fail(ESCOIN_EINVAL, "jit: code object segment out of bounds");
+    }
+    for (unsigned i = 0; i < eh.e_shnum; ++i) {
+      Elf64_Shdr sh;
+      std::memcpy(&sh, elf.data() + eh.e_shoff + (size_t)i * sizeof(sh), sizeof(sh));
+      if (sh.sh_type != SHT_NOBITS && sh.sh_type != SHT_NULL && (sh.sh_offset > n || sh.sh_size > n - sh.sh_offset))
+        return fail(ESCOIN_EINVAL, "jit: code object section out of bounds");
+    }
+  }
   JitModule m;
   ESCOIN_HIP_TRY(hipModuleLoadData(&m.module, elf.data()));
   hipFunction_t locator = nullptr;
@@ -315,7 +338,7 @@ int jit_wrap(const std::vector<uint32_t> &code, std::vector<char> *elf) {
 }
 
 int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream, std::vector<char> *keep_elf) {
-  static const bool wrap = !(getenv("ESCOIN_JIT_WRAP") && atoi(getenv("ESCOIN_JIT_WRAP")) == 0);
+  static const bool wrap = (ESC_KNOB("JIT_WRAP", 1) != 0);
   std::vector<char> elf;
   int rc = wrap ? jit_wrap(code, &elf) : ESCOIN_EHIP;
   if (rc == ESCOIN_OK) rc = jit_load_elf(elf, code.size() * 4, out, stream);

@@ -1,9 +1,12 @@
 // stream_builder.cpp -- see stream_builder.h
 #include "stream_builder.h"
 
+#include "knobs.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <system_error>
 #include <thread>
 #include <cstdlib>
 #include <cstring>
@@ -84,7 +87,7 @@ Tiling tile_with(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int 
   // 64-quad row) needs no row pitch: the planes are packed to the quads that exist.  Lanes past the row
   // read the next channel's quads (theirs are results nobody stores); the fill moves 23 % fewer bytes.
   if (g.sub == 1 && g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && !t.band_mode && t.nseg == 1 && t.tr == 1 &&
-      !(getenv("ESCOIN_PACK_ROW") && atoi(getenv("ESCOIN_PACK_ROW")) == 0))
+      (ESC_KNOB("PACK_ROW", 1) != 0))
     t.plane_ch_floats = std::min(t.plane_ch_floats, (g.W + 7) / 8 * 8);   // (whole 32 bytes: the stream's row offsets)
   const int per_ch = t.plane_ch_floats * 4;
   // (row offsets travel as offset / 32 in 11-bit fields of the stream: 64 KiB per plane buffer)
@@ -112,7 +115,7 @@ double launch_cost_us(const ConvGeom &g, const Tiling &t, int n_cu) {
   const double walk = rows * nonempty * 0.060 + rows * g.KW * t.G * d * 0.018;
   // (planes land at 18-20 GB/s per CU with every CU staging: GoogLeNet's 28 x 28 layers read 154 MB in
   // 34.6 us with the walk and the stores switched off; rounds 1-2 assumed 50)
-  static const double dma_bytes_per_us = (getenv("ESCOIN_DMA_GBPS") ? atof(getenv("ESCOIN_DMA_GBPS")) : 19.0) * 1e3;
+  static const double dma_bytes_per_us = (ESC_KNOB_F("DMA_GBPS", 19.0)) * 1e3;
   const double dma = (double)g.Cg * t.plane_ch_floats * 4.0 / dma_bytes_per_us;
   const double epilogue = 0.15 * t.G * t.tpl;
   const double per_tile = t.n_icb * 1.2 + std::max(walk, dma) + epilogue;
@@ -201,7 +204,7 @@ Tiling choose_tiling(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, 
       const double used = t.band_mode ? (double)t.H : (double)t.H * (t.rows_per_wg / t.H);
       return used * t.W / (rows * t.RS);
     };
-    static const bool no_recut = getenv("ESCOIN_NORECUT") != nullptr;
+    static const bool no_recut = ESC_KNOB_SET("NORECUT");
     for (int w = 1; w <= 256 && w <= hw; ++w) {
       if (hw % w != 0 || w == g.W) continue;
       if (g.W % 4 == 0 && (w % 4 != 0 || no_recut)) continue;   // never trade aligned rows for straddling ones
@@ -259,7 +262,7 @@ std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const
   std::vector<uint32_t> slot(static_cast<size_t>(n_ocg) * G);
   for (int o = 0; o < n_ocg; ++o)
     for (int gl = 0; gl < G; ++gl) slot[(size_t)o * G + gl] = (uint32_t)std::min(o * G + gl, Mg - 1);
-  static const bool enabled = !(getenv("ESCOIN_BALANCE") && atoi(getenv("ESCOIN_BALANCE")) == 0);
+  static const bool enabled = (ESC_KNOB("BALANCE", 1) != 0);
   if (!enabled || g.KW == 1 || t.oc_waves < 2 || Mg < 2 * G) return slot;
   const double kGroupCost = group_cost, kRecordCost = record_cost;
   const int rows_per_blk = t.icb * g.KH;
@@ -402,12 +405,20 @@ std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const
   if (n_thr <= 1) {
     for (int blk0 : cols) deal_column(blk0);
   } else {
+    // (the calling thread works too; a thread the system refuses to create is simply one worker fewer)
     std::vector<std::thread> pool;
     std::atomic<size_t> next{0};
-    for (size_t th = 0; th < n_thr; ++th)
-      pool.emplace_back([&]() {
-        for (size_t i = next.fetch_add(1); i < cols.size(); i = next.fetch_add(1)) deal_column(cols[i]);
-      });
+    auto worker = [&]() {
+      for (size_t i = next.fetch_add(1); i < cols.size(); i = next.fetch_add(1)) deal_column(cols[i]);
+    };
+    for (size_t th = 1; th < n_thr; ++th) {
+      try {
+        pool.emplace_back(worker);
+      } catch (const std::system_error &) {
+        break;
+      }
+    }
+    worker();
     for (auto &th : pool) th.join();
   }
   // slots past the last channel of a partly filled oc-group repeat a valid channel

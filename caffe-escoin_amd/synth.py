@@ -61,17 +61,106 @@ def out_hw(s):
     return oh, ow
 
 
-def pruned_weights(s, seed):
-    """(M, C/g, KH, KW) float32 with exactly round(sparsity*count) zeros per group."""
+SPARSITY_DISTS = ("uniform", "channel", "zero_inputs", "filters_tail")
+
+
+def _row_counts(weights, total, cap):
+    """Integer nonzero counts per row, proportional to `weights`, summing to `total` exactly, none above `cap`
+    (largest remainders first; what a capped row cannot take goes to the others)."""
+    w = np.asarray(weights, np.float64).copy()
+    counts = np.zeros(len(w), np.int64)
+    left = int(total)
+    for _ in range(64):
+        if left <= 0 or w.sum() <= 0:
+            break
+        share = w / w.sum() * left
+        add = np.minimum(np.floor(share).astype(np.int64), cap - counts)
+        counts += add
+        left -= int(add.sum())
+        w = np.where(counts >= cap, 0.0, w)
+        if int(add.sum()) == 0:
+            # less than one per open row is left: hand the rest out one by one, largest share first
+            order = np.argsort(-(share - np.floor(share)), kind="stable")
+            for i in order:
+                if left <= 0:
+                    break
+                if counts[i] < cap and w[i] > 0:
+                    counts[i] += 1
+                    left -= 1
+            if left > 0:
+                for i in np.argsort(-counts, kind="stable")[::-1]:
+                    take = min(left, cap - counts[i])
+                    counts[i] += take
+                    left -= take
+                    if left <= 0:
+                        break
+            break
+    return counts
+
+
+def pruned_weights(s, seed, dist="uniform"):
+    """(M, C/g, KH, KW) float32 with exactly round(sparsity*count) zeros per group.
+
+    dist -- how the nonzeros lie (the total per group is the same for all, so the algorithmic bytes and flops of a
+    layer do not depend on it):
+      "uniform"       unstructured random pruning (the default; every BASELINE config)
+      "channel"       per-OUTPUT-channel density drawn from U(0, 2 d) -- what magnitude pruning leaves (the nets the
+                      reference runs are SkimCaffe-pruned, run.sh:14: channels differ widely in density)
+      "zero_inputs"   20 % of the INPUT channels are entirely zero; the others carry the same total
+      "filters_tail"  10 % of the filters (output channels) are entirely zero, 5 % hold four times the mean
+                      density (a heavy tail), the rest share what is left
+    """
     cg = s.C // s.group
-    per_group = (s.M // s.group) * cg * s.KH * s.KW
+    mg = s.M // s.group
+    kk = s.KH * s.KW
+    per_group = mg * cg * kk
     w = uniform(seed, per_group * s.group).copy()
     # never let a kept weight be exactly zero (dense->CSR keeps != 0 only)
     w[w == 0.0] = np.float32(0.5)
+    if dist == "uniform":
+        for g in range(s.group):
+            nzero = int(round(s.sparsity * per_group))
+            rank = np.argsort(hash_u64(seed ^ 0x5EED5EED, g * per_group, per_group), kind="stable")
+            w[g * per_group + rank[:nzero]] = 0.0
+        return w.reshape(s.M, cg, s.KH, s.KW)
+    if dist not in SPARSITY_DISTS:
+        raise ValueError("unknown sparsity distribution %r" % (dist,))
+    d = 1.0 - s.sparsity
     for g in range(s.group):
-        nzero = int(round(s.sparsity * per_group))
-        rank = np.argsort(hash_u64(seed ^ 0x5EED5EED, g * per_group, per_group), kind="stable")
-        w[g * per_group + rank[:nzero]] = 0.0
+        keep_total = per_group - int(round(s.sparsity * per_group))
+        u = (hash_u64(seed ^ 0xD157, g * (mg + cg), mg + cg) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+        u_m, u_c = u[:mg], u[mg:]
+        in_ok = np.ones(cg, bool)
+        if dist == "channel":
+            row_w = 2.0 * d * u_m + 1e-9
+        elif dist == "zero_inputs":
+            row_w = np.ones(mg)
+            n_dead = int(round(0.2 * cg)) if cg >= 5 else 0
+            in_ok[np.argsort(u_c, kind="stable")[:n_dead]] = False
+        else:       # filters_tail
+            order = np.argsort(u_m, kind="stable")
+            n_dead = int(round(0.1 * mg)) if mg >= 10 else 0
+            n_tail = max(1, int(round(0.05 * mg))) if mg >= 4 else 0
+            row_w = np.ones(mg)
+            row_w[order[:n_dead]] = 0.0
+            tail = order[n_dead:n_dead + n_tail]
+            # the tail rows at 4 d each; the others share the rest evenly
+            rest = max(1, mg - n_dead - n_tail)
+            tail_share = min(4.0 * d, 1.0) * cg * kk
+            other_share = max(0.0, (keep_total - tail_share * n_tail) / rest)
+            row_w[tail] = tail_share / max(other_share, 1e-9)
+        cap = int(in_ok.sum()) * kk
+        counts = _row_counts(row_w, min(keep_total, cap * int((row_w > 0).sum())), cap)
+        allowed = np.repeat(in_ok, kk)            # positions of a row a nonzero may take
+        pos_all = np.nonzero(allowed)[0]
+        for m in range(mg):
+            base = g * per_group + m * cg * kk
+            h = hash_u64(seed ^ 0x5EED5EED, base, cg * kk)
+            keep = pos_all[np.argsort(h[pos_all], kind="stable")[:int(counts[m])]]
+            row = w[base:base + cg * kk]
+            mask = np.zeros(cg * kk, bool)
+            mask[keep] = True
+            row[~mask] = 0.0
     return w.reshape(s.M, cg, s.KH, s.KW)
 
 

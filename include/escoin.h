@@ -66,9 +66,10 @@ extern "C" {
 #define ESCOIN_KERNEL_DENSE 3   /* implicit-GEMM on the fp32 matrix cores (MFMA)  */
 #define ESCOIN_KERNEL_JIT 4     /* LDS-staged tiles; the weight walk is machine code
                                    WeightAlign generated from the sparsity pattern
-                                   (AUTO picks it per plan from what WeightAlign knows:
-                                   code bytes against the L2 of an XCD, nonzeros per row;
-                                   escoin_capi.hip choose_walk)                       */
+                                   (what AUTO runs on every stride-1 layer -- and on
+                                   1x1 / stride-2 layers -- that it keeps on the sparse
+                                   path; the one exception is the small-launch rule,
+                                   escoin_plan_stat "small_launch_rule")              */
 
 /* Geometry of one ConvolutionLayer: what LayerSetUp/Reshape derive from
  * ConvolutionParameter + the bottom shape (base_conv_layer.cpp:276-530). */
@@ -126,7 +127,13 @@ ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
  *                  stores -- for a blob nothing on the device reads next (3-4 % on a sequence of
  *                  independent layers); 0 / -1 (default): ordinary stores, which leave the blob in
  *                  L2 / Infinity Cache for the layer that consumes it (as the reference's kernels
- *                  do, math_functions.cu:524-587).  Results are the same either way. */
+ *                  do, math_functions.cu:524-587).  Results are the same either way;
+ *   "max_launch_bytes" = bottom-blob bytes one launch of the LDS-tiled kernels may cover (0 = the 4 GiB range of
+ *                  a buffer descriptor; larger batches run as consecutive sub-batch launches).  Results do not
+ *                  depend on it; tests use it to exercise the sub-batch loop on small inputs.
+ * Environment: the product build reads ESCOIN_VERBOSE (diagnostics on stderr) and TMPDIR (temporary file of the
+ * code object manager's fallback path) and nothing else -- no environment variable can change a result
+ * ("Environment"; csrc/knobs.h for the experiment flavours built by tools/mkabl.sh). */
 ESCOIN_API int escoin_plan_set_option(escoin_plan *plan, const char *key, int value);
 
 /* WeightAlign(): dense blobs_[0] (M x C/g x KH x KW, zeros = pruned) -> per-group CSR
@@ -160,23 +167,28 @@ ESCOIN_API size_t escoin_plan_workspace_bytes(const escoin_plan *plan);
 /* The aligned form as one relocatable byte blob: the CSR and -- for a generated-code plan -- the
  * channel deal, the unit table and the code object WeightAlign produced.  The reference recomputes
  * its aligned form on every weight load (Net::CopyTrainedLayersFrom -> WeightAlign, net.cpp:819);
- * here WeightAlign compiles code (5-165 ms per layer), so a deployment persists it once.
+ * here WeightAlign also compiles code (2-25 ms per layer since round 4, profiles/r04_weight_align.md), and a
+ * deployment may persist the result once.
  *   export: buf == NULL queries the size (*bytes); otherwise writes *bytes <= capacity bytes.
  *   import: restores the CSR (always) and, when the blob's code section was written by this library
- *           build for this geometry / batch / option set on a device with the same CU count, loads the
- *           persisted code object as it is -- no channel deal, no generator pass, no assembler
+ *           build for this geometry / batch / tiling_batch, for the same split of the conv groups between the
+ *           sparse and the dense kernel (options dense_threshold_pct, dense_gate, conv_mode decide it) and on a
+ *           device of the same ISA and CU count, loads the persisted code object as it is -- no channel deal, no generator pass, no assembler
  *           (escoin_plan_stat(plan, "import_fast") == 1); otherwise it aligns from the CSR like
- *           escoin_plan_set_csr.  Plan options must be set before the import, as before weight_align. */
+ *           escoin_plan_set_csr -- also when the device refuses the persisted code object.  Plan options must be
+ *           set before the import, as before weight_align.  Every field of the blob is range-checked before it
+ *           sizes or indexes anything; a malformed blob gives ESCOIN_EINVAL, never a crash. */
 ESCOIN_API int escoin_plan_export_aligned(const escoin_plan *plan, void *buf, size_t capacity, size_t *bytes);
 ESCOIN_API int escoin_plan_import_aligned(escoin_plan *plan, const void *buf, size_t bytes, void *stream);
 
 /* Integer facts about an aligned plan (negative = error): "align_us" wall time of the last
  * weight_align / set_csr / import_aligned, "code_bytes" generated machine code on the device,
  * "device_bytes", "import_fast", "jit_rows", "jit_records", "lds_bytes", "workgroup_columns",
- * "kernel_choice" (the ESCOIN_KERNEL_* id AUTO resolved to for the sparse groups), "tuned_small" (KERNEL_AUTO
- * timed the LDS-tiled and the generic kernel at WeightAlign because the whole launch is under 64 MFLOP -- the
- * reference's SCONV mode runs image by image, conv_layer.cu:16-26 --: 0 no, 1 and kept the tiled one, 2 and took
- * the generic one). */
+ * "kernel_choice" (the ESCOIN_KERNEL_* id AUTO resolved to for the sparse groups), "small_launch_rule" (KERNEL_AUTO's
+ * rule for pointwise launches under 64 MFLOP that fit one round of workgroups -- the reference's SCONV mode runs
+ * image by image, conv_layer.cu:16-26 --: 0 not considered, 1 kept generated code, 2 took the generic kernel; a
+ * function of the options, the weights and the batch only: the same in every process), "streamk" / "streamk_gave_up"
+ * (dense kernel; a give-up also makes the next escoin_forward on the plan fail with ESCOIN_EHIP). */
 ESCOIN_API long escoin_plan_stat(const escoin_plan *plan, const char *key);
 
 /* Name of the device kernel the plan launches (the symbol rocprofv3 reports). */

@@ -133,3 +133,30 @@ def test_package_is_importable_under_alias():
     import __graft_entry__ as ge
     p = ge.load_package()
     assert p.__name__ == "caffe_escoin_amd" and hasattr(p, "synth") and hasattr(p, "Plan")
+
+
+def test_product_library_reads_no_experiment_switches():
+    """The product build reads ESCOIN_VERBOSE (diagnostics) and TMPDIR and nothing else: every tuning switch is a
+    compile-time constant there and the wrong-result switches (ESCOIN_DBG, ESCOIN_JIT_ABL, ESCOIN_DENSE_ABL) exist in
+    the -DESCOIN_ABLATIONS flavour only (csrc/knobs.h, tools/mkabl.sh).  The names must not even
+    be in the binary: a leftover environment variable cannot change a result."""
+    import re
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_path = os.path.join(ROOT, "caffe-escoin_amd", "libescoin_hip.so")
+    assert os.path.exists(lib_path)
+    out = subprocess.run(["strings", "-n", "6", lib_path], stdout=subprocess.PIPE, check=True).stdout.decode()
+    names = set(re.findall(r"\bESCOIN_[A-Z0-9_]+\b", out))
+    assert names <= {"ESCOIN_VERBOSE"}, sorted(names - {"ESCOIN_VERBOSE"})
+    assert not re.search(r"ESCOIN_JIT_ABL|ESCOIN_DBG|ESCOIN_DENSE_ABL|ESCOIN_PROF", out)
+    # the sources agree: getenv appears only in knobs.h (the non-product flavours), for ESCOIN_VERBOSE and for TMPDIR
+    csrc = os.path.join(ROOT, "caffe-escoin_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".cpp", ".h")) or fn == "knobs.h":
+            continue
+        for line in open(os.path.join(csrc, fn)):
+            for m in re.finditer(r'getenv\("([A-Z_0-9]+)"\)', line):
+                assert m.group(1) in ("ESCOIN_VERBOSE", "TMPDIR"), (fn, line.strip())
+    # and no A/B artefact sits in the package directory (it would ship with every push to a GPU box)
+    extra = [f for f in os.listdir(os.path.join(ROOT, "caffe-escoin_amd")) if f.endswith(".so") and f != "libescoin_hip.so"]
+    assert not extra, extra

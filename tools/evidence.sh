@@ -9,7 +9,7 @@
 #   EVIDENCE_ONLY=stamp: the stamp profile only
 set -u
 TAG=${1:-r04}
-ABL=${2:-$PWD/caffe-escoin_amd/libescoin_abl.so}
+ABL=${2:-$PWD/tools/ab/libescoin_abl.so}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 if [ "${EVIDENCE_ONLY:-}" != "stamp" ]; then
@@ -27,10 +27,10 @@ done
 [ "${EVIDENCE_ONLY:-}" = "stamp" ] && exit 0
 for L in res2 res3 res4 res5; do
   for a in 0 1 2 4 8 3 7; do
-    echo "ABL=$a $(ESCOIN_JIT_ABL=$a ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 100 2>&1 | tail -1)" >> $OUT/jit_abl_$L.txt
+    echo "ABL=$a $(ESCOIN_LIB=$ABL ESCOIN_JIT_ABL=$a ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 100 2>&1 | tail -1)" >> $OUT/jit_abl_$L.txt
   done
   for d in 1 2 3 4 128 64; do
-    echo "DBG=$d $(ESCOIN_DBG=$d ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 100 2>&1 | tail -1)" >> $OUT/jit_abl_$L.txt
+    echo "DBG=$d $(ESCOIN_LIB=$ABL ESCOIN_DBG=$d ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 100 2>&1 | tail -1)" >> $OUT/jit_abl_$L.txt
   done
   echo "abl $L done"
 done

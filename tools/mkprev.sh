@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the committed (HEAD) state of the library as caffe-escoin_amd/libescoin_prev.so next to the
+# Builds the committed (HEAD) state of the library as tools/ab/libescoin_prev.so (not in the package directory) beside the
 # working tree's build, for a same-box A/B with tools/ab.sh.  HEAD is checked out into a scratch
 # worktree: the working tree, its stashes and its own build are never touched.
 set -e
@@ -9,5 +9,6 @@ git worktree remove --force $W 2> /dev/null || true
 git worktree add --detach $W HEAD > /dev/null
 trap 'git worktree remove --force '$W' > /dev/null 2>&1 || true' EXIT
 make -C $W/caffe-escoin_amd/csrc -j4 > /dev/null
-cp $W/caffe-escoin_amd/libescoin_hip.so caffe-escoin_amd/libescoin_prev.so
-echo "caffe-escoin_amd/libescoin_prev.so = $(git rev-parse --short HEAD)"
+mkdir -p tools/ab
+cp $W/caffe-escoin_amd/libescoin_hip.so tools/ab/libescoin_prev.so
+echo "tools/ab/libescoin_prev.so = $(git rev-parse --short HEAD)"
