@@ -201,11 +201,22 @@ def build_layers(be, pkg, synth, shapes, rank, world, args=None, dist_on=None):
             if hasattr(plan, "stat"):
                 setup["code_bytes"] += plan.stat("code_bytes")
                 setup["device_bytes"] += plan.stat("device_bytes")
+                # balance of the channel deal: barrier-weighted slowest / mean wave, and the worst block (x 1000; 0 for
+                # a plan restored from a persisted code object)
+                setup.setdefault("deal", []).append((s.name, plan.stat("deal_slowest_over_mean_x1000"), plan.stat("deal_worst_block_x1000"),
+                                                     plan.stat("code_bytes")))
             bias = synth.bias_vector(s, 2000 + 31 * lid)
             bias = torch.from_numpy(bias).to(be.device) if bias is not None else None
             layers.append((s, plan, bias, si, lid))
             lid += 1
     return layers, t_bcast, setup
+
+
+def _group_deal(deal):
+    out = {}
+    for name, a, b, c in deal:
+        out.setdefault(name, []).append((a, b, c))
+    return list(out.items())
 
 
 def last_layer_of_shape(layers):
@@ -708,6 +719,11 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
                             "first_load_ms": None if setup.get("first_load_ms") is None else round(setup["first_load_ms"], 2),
                             "layers": len(setup["align_ms"])},
         "generated_code_bytes": setup["code_bytes"], "plan_device_bytes": setup["device_bytes"],
+        # per distinct layer shape: how evenly WeightAlign's channel deal loads the waves that meet at a block's barrier
+        # (slowest wave / mean wave, weighted over all blocks; the worst single block), and the largest code object
+        "channel_deal": [{"layer": n, "slowest_over_mean": max(v[0] for v in vs) / 1000.0, "worst_block": max(v[1] for v in vs) / 1000.0,
+                          "max_code_bytes": max(v[2] for v in vs)}
+                         for n, vs in _group_deal(setup.get("deal", []))],
         "weight_receive_ms": receive,
         "backend": be.name, "dist_backend": (be.dist_backend if test_be(be) else args.dist_backend) if dist_on else None,
         "buffers": "one bottom/top pair per layer (no launch re-reads the previous launch's input)",

@@ -298,12 +298,13 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
   // knows -- the same weights, options and batch give the same kernel in every process:
   //   pointwise layers only (the 3x3 / 5x5 layers keep generated code at every batch: the generic kernel needs
   //   16-81 us where code needs 12-16), a launch of one round (tiles x columns <= CUs) under 64 MFLOP;
-  //   generic  ~ max(kGenFloor, kGenBase + kGenPerMflop x MFLOP)            us
-  //   code     ~ kCodeBase + max(walk, kCodePerBlock x blocks per tile)      us, walk = a wave's vector instructions
-  //              per tile at one instruction per 5.4 cycles
-  //   generic when it is more than a tenth faster by these estimates.
-  // Constants fitted to profiles/r05_small_launch_fit.md (tools/small_launch_fit.py: both kernels forced, 1-32 images
-  // of every distinct GoogLeNet 1x1 shape).
+  //   generic  ~ max(7.0, 5.8 + 0.125 r, 6.2 + waves x (0.143 + 0.0473 r) / 1000)   us; r = nonzeros per output row (the
+  //              CSR row a wave walks with scalar loads: a latency chain), waves = N x M x ceil(OH OW / 64)
+  //   code     ~ 7.6 + (0.6 chained | 1.1 one call per block) x blocks per tile + 0.1 x MB of blobs    us
+  //   the kernel with the lower estimate.
+  // Fitted to 180 cells (profiles/r05_small_launch_fit.md; tools/small_launch_fit.py: both kernels forced, 1-32 images
+  // of every distinct GoogLeNet 1x1 shape): the models are within 6 % (code) / 12 % (generic) rms of the measurements
+  // and the rule's pick is at most 12.7 % behind the faster kernel, two cells of 180 more than 10 %.
   p->small_rule = 0;
   if (p->kernel_choice == ESCOIN_KERNEL_AUTO && p->tiled.enabled && p->n_dense_groups == 0 &&
       (p->tiling_batch <= 0 || p->tiling_batch == g.d.N) && g.d.KH == 1 && g.d.KW == 1) {
@@ -312,15 +313,12 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
     const long tiles = t.band_mode ? (long)g.d.N * t.bands : ((long)g.d.N + t.nseg - 1) / t.nseg;
     const long wgs = tiles * t.n_ocblk * G;
     if (flops < 64e6 && wgs <= tiled_device_cus()) {
-      constexpr double kGenFloor = 7.0, kGenBase = 4.5, kGenPerMflop = 0.55;
-      constexpr double kCodeBase = 6.5, kCodePerBlock = 0.85, kNsPerValu = 2.45;
-      const double dens = (double)nnz / (per_group * G);
-      // vector instructions of a wave per tile: two packed FMAs per nonzero and tile quad; its G channels' nonzeros
-      const double quads = (t.tpl == 1 || t.tr * t.nseg <= t.rows_per_slab) ? 1.0 : 2.0;
-      const double walk_us = (double)g.Cg * t.G * dens * 2.0 * quads * kNsPerValu * 1e-3;
-      const double t_code = kCodeBase + std::max(walk_us, kCodePerBlock * t.n_icb);
-      const double t_gen = std::max(kGenFloor, kGenBase + kGenPerMflop * flops * 1e-6);
-      p->small_rule = t_gen < 0.9 * t_code ? 2 : 1;
+      const double r = (double)nnz / (double)g.d.M;
+      const double waves = (double)g.d.N * g.d.M * std::ceil((double)g.OH * g.OW / 64.0);
+      const double mb = 4.0 * g.d.N * ((double)g.d.C * g.d.H * g.d.W + (double)g.d.M * g.OH * g.OW) * 1e-6;
+      const double t_gen = std::max(std::max(7.0, 5.8 + 0.125 * r), 6.2 + waves * (0.143 + 0.0473 * r) * 1e-3);
+      const double t_code = 7.6 + (p->tiled.jit_chain ? 0.6 : 1.1) * t.n_icb + 0.1 * mb;
+      p->small_rule = t_gen < t_code ? 2 : 1;
       if (getenv("ESCOIN_VERBOSE"))
         fprintf(stderr, "[escoin] small launch (%.1f MFLOP, %ld workgroups, %d blocks): code ~%.1f us, generic ~%.1f us -> %s\n",
                 flops * 1e-6, wgs, t.n_icb, t_code, t_gen, p->small_rule == 2 ? "generic" : "code");
