@@ -665,6 +665,10 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     roofline = {"bound": "hbm", "kernel": dom_label, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_provenance": provenance,
+                # PMC bytes (FETCH_SIZE x 2 + WRITE_SIZE, the fabric side of the L2s: Infinity-Cache hits included) over
+                # the algorithmic bytes, per launch of the dominant kernel over the step: > 1 = re-reads (halo, several
+                # workgroup columns, XCD grouping) and generated code; profiles/r05_mall_share.md says which of it is HBM
+                "traffic_over_alg": round(traffic / (dom["bytes"] / dom["launches"]), 3) if traffic else None,
                 "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                 "launches_per_step": dom["launches"],
                 # per-launch events in `sampled_steps` of the timed steps; one event costs `event_us`

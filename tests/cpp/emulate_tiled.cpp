@@ -346,11 +346,12 @@ static int run(const Case &cs, bool use_jit) {
     jo.depth_one_tile = (cs.N & 1) ? 5 + cs.N % 9 : 5;
     // plane DMA from inside the code wherever one wave owns an oc-group (whatever the table's size: the
     // product bounds it, the emulation does not need to)
-    if (t.pix_waves == 1 && t.waves == 8) {
+    if (t.pix_waves == 1 && (t.waves == 8 || t.waves == 4)) {
       int padded = 0;
       jo.dma.period = jit::dma_period(t.plane_ch_floats / 4, 1 << 24, 0.0, &padded);
       jo.dma.on = jo.dma.period > 0 && padded == t.plane_ch_floats / 4;
       jo.dma.qpc = t.plane_ch_floats / 4;
+      jo.dma.waves = t.waves;
       jo.dma.chan_bytes = (uint32_t)(cs.H * cs.W * 4);
       jo.dma.nt = (cs.N & 2) != 0;
       jo.dma.spread_pct = 40 + 10 * (cs.M % 5);
@@ -455,7 +456,7 @@ static int run(const Case &cs, bool use_jit) {
             const uint32_t rel = pcs.m0 - fill_base;
             if (rel % 1024 || (int)(rel / 1024) >= n_instr) { printf("jit dma: bad LDS address m0=%u fill_base=%u n_instr=%d nb=%d\n", pcs.m0, fill_base, n_instr, nb); return 3; }
             const int i = (int)(rel / 1024);
-            if (i % 8 != ocg % 8) { printf("jit dma: piece %d issued by wave %d\n", i, ocg % 8); return 3; }
+            if (i % jdma.waves != ocg % jdma.waves) { printf("jit dma: piece %d issued by wave %d\n", i, ocg % jdma.waves); return 3; }
             seen[i]++;
             if (pcs.nt != jdma.nt) { printf("jit dma: nt flag\n"); return 3; }
             for (int lane = 0; lane < 64; ++lane) {
@@ -577,7 +578,7 @@ static int run(const Case &cs, bool use_jit) {
                   const uint32_t rel = pcs.m0 - dctx.fill_base;
                   if (rel % 1024 || (int)(rel / 1024) >= n_instr) { printf("jit dma: bad LDS address m0=%u fill_base=%u n_instr=%d nb=%d\n", pcs.m0, dctx.fill_base, n_instr, nb); return 3; }
                   const int i = (int)(rel / 1024);
-                  if (i % 8 != ocg % 8) { printf("jit dma: piece %d issued by wave %d\n", i, ocg % 8); return 3; }
+                  if (i % jdma.waves != ocg % jdma.waves) { printf("jit dma: piece %d issued by wave %d\n", i, ocg % jdma.waves); return 3; }
                   seen[i]++;
                   if (pcs.nt != jdma.nt) { printf("jit dma: nt flag\n"); return 3; }
                   for (int lane = 0; lane < 64; ++lane) {
@@ -759,6 +760,12 @@ int main() {
       {4, 45, 7, 7, 24, 3, 3, 1, 1, 1, 0.85f, 8, 8192},
       {3, 20, 56, 56, 8, 3, 3, 1, 1, 1, 0.9f, 8, 32768},
       {9, 37, 7, 7, 64, 1, 1, 0, 0, 1, 0.9f, 8, 4096, 256},
+      // two 4-wave workgroups per CU (sconv_tiled.hip, half-workgroup rule): the pieces of a block go round four waves
+      {4, 48, 28, 28, 64, 1, 1, 0, 0, 1, 0.95f, 4, 32768, 4},
+      {3, 40, 28, 28, 96, 1, 1, 0, 0, 1, 0.9f, 4, 8192, 2},
+      {2, 21, 14, 14, 16, 3, 3, 1, 1, 1, 0.8f, 4, 16384},
+      {3, 30, 28, 28, 128, 1, 1, 0, 0, 1, 0.9f, 4, 32768, 1},     // ... 128 channels in one column: one quad per lane, four bands of 25 rows
+      {2, 26, 28, 28, 176, 1, 1, 0, 0, 1, 0.93f, 4, 8192, 1},     // ... 176: 44 channels per wave, several blocks
   };
   int bad = 0;
   for (const Case &c : cases) {
