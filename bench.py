@@ -203,8 +203,11 @@ def build_layers(be, pkg, synth, shapes, rank, world, args=None, dist_on=None):
                 setup["device_bytes"] += plan.stat("device_bytes")
                 # balance of the channel deal: barrier-weighted slowest / mean wave, and the worst block (x 1000; 0 for
                 # a plan restored from a persisted code object)
-                setup.setdefault("deal", []).append((s.name, plan.stat("deal_slowest_over_mean_x1000"), plan.stat("deal_worst_block_x1000"),
-                                                     plan.stat("code_bytes")))
+                try:
+                    setup.setdefault("deal", []).append((s.name, plan.stat("deal_slowest_over_mean_x1000"), plan.stat("deal_worst_block_x1000"),
+                                                         plan.stat("code_bytes")))
+                except Exception:       # (an older build of the library under ESCOIN_LIB: tools/ab.sh)
+                    pass
             bias = synth.bias_vector(s, 2000 + 31 * lid)
             bias = torch.from_numpy(bias).to(be.device) if bias is not None else None
             layers.append((s, plan, bias, si, lid))

@@ -177,22 +177,6 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
       }
     }
   }
-  // The same for a pointwise layer cut into row bands (28 x 28 as 98 x 8 on a four-wave workgroup, sconv_tiled.hip's
-  // half-workgroup rule): with one quad per lane a band is 32 rows instead of 64 -- twice the tiles, each of the same
-  // lanes' worth of work -- and 97 .. 192 output channels fit one column of four waves, so the input is staged once.
-  if (one_tile_ok && waves_per_wg == 4 && g.sub == 1 && g.KH == 1 && g.KW == 1 && g.pad_h == 0 && g.pad_w == 0 && best.band_mode &&
-      best.pix_waves == 1 && best.n_ocblk > 1) {
-    for (int passes = 1; passes < best.n_ocblk; ++passes) {
-      const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, passes, 0, 1);
-      if (!t.ok || t.G < 1 || t.n_ocblk >= best.n_ocblk || !t.band_mode || t.pix_waves != 1) continue;
-      const double c = launch_cost_us(g, t, n_cu);
-      if (c < best_cost * 0.97) {
-        best = t;
-        best_cost = c;
-        break;
-      }
-    }
-  }
   return best;
 }
 

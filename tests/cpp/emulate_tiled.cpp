@@ -764,8 +764,8 @@ int main() {
       {4, 48, 28, 28, 64, 1, 1, 0, 0, 1, 0.95f, 4, 32768, 4},
       {3, 40, 28, 28, 96, 1, 1, 0, 0, 1, 0.9f, 4, 8192, 2},
       {2, 21, 14, 14, 16, 3, 3, 1, 1, 1, 0.8f, 4, 16384},
-      {3, 30, 28, 28, 128, 1, 1, 0, 0, 1, 0.9f, 4, 32768, 1},     // ... 128 channels in one column: one quad per lane, four bands of 25 rows
-      {2, 26, 28, 28, 176, 1, 1, 0, 0, 1, 0.93f, 4, 8192, 1},     // ... 176: 44 channels per wave, several blocks
+      {3, 30, 28, 28, 128, 1, 1, 0, 0, 1, 0.9f, 4, 32768, 1},     // ... 128 channels: two columns of four waves
+      {2, 26, 28, 28, 176, 1, 1, 0, 0, 1, 0.93f, 4, 8192, 1},     // ... 176 channels, several blocks
   };
   int bad = 0;
   for (const Case &c : cases) {

@@ -1145,3 +1145,59 @@ def test_blobs_that_start_off_a_16_byte_boundary(pkg, oracle, synth, torch_cuda)
                 assert rel_err(got, want) <= TOL, "%s via %s, %d floats off: %g" % (s.name, plan.kernel_name, off, rel_err(got, want))
                 assert (o[:off] == 5.0).all() and (o[off + want.size:] == 5.0).all(), (s.name, plan.kernel_name, off)
             plan.close()
+
+
+@pytest.mark.parametrize("dist", ["channel", "zero_inputs", "filters_tail"])
+def test_skewed_sparsity_distributions(pkg, oracle, synth, torch_cuda, dist):
+    """A pruned model's weights are not uniformly sparse (the reference's nets are SkimCaffe-pruned, run.sh:14): per-output-
+    channel densities from U(0, 2d), a fifth of the input channels all zero, a tenth of the filters all zero with a heavy
+    tail of rows at 4d (synth.pruned_weights(..., dist); the same total count as the uniform case).  Every BASELINE 3x3 /
+    5x5 shape and two pointwise ones, tiled as for their config batch, on generated code and on the stream kernel, against
+    the oracle; the channel deal must stay a permutation (every output channel written: the comparison covers them all) and
+    generated code must not fall off its size limit."""
+    torch = torch_cuda
+    shapes = list(synth.resnet50_3x3(N=3)) + list(synth.alexnet(N=3)) + [synth.googlenet_1x1(N=3)[5], synth.googlenet_1x1(N=3)[25]]
+    for k, s in enumerate(shapes):
+        w = synth.pruned_weights(s, 700 + k, dist)
+        assert int((w != 0).sum()) == synth.nnz_of(s)
+        b, x = synth.bias_vector(s, 720 + k), synth.activations(s, 740 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
+        want = oracle.conv_forward(g, x, w, b, gate=False, threads=4)
+        tb = 256 if s.name.startswith(("res", "incep")) else 128
+        for kernel in (pkg.KERNEL_JIT, pkg.KERNEL_TILED):
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel, tiling_batch=tb)
+            plan.weight_align(w)
+            if kernel == pkg.KERNEL_JIT:
+                assert "jit" in plan.kernel_name and plan.stat("code_bytes") > 0, (s.name, plan.kernel_name)
+                assert plan.stat("deal_slowest_over_mean_x1000") >= 1000
+            dev = torch.device("cuda:0")
+            got = plan.forward(torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev) if b is not None else None).cpu().numpy()
+            plan.close()
+            assert rel_err(got, want) <= TOL, "%s %s via kernel %d: %g" % (s.name, dist, kernel, rel_err(got, want))
+
+
+@pytest.mark.parametrize("n", [257, 293])
+def test_batches_off_the_tilings_grid(pkg, oracle, synth, torch_cuda, n):
+    """A drop-in sees arbitrary batches (the reference calls the layer image by image in SCONV mode, conv_layer.cu:19-26;
+    shard.py allows uneven shards): 257 and 293 images of res4 / res5 -- one more tile than the 256 CUs' round, a last tile
+    that is not full -- through KERNEL_AUTO; every image against the generic kernel (bit-exact to the reference's order),
+    the last three against the oracle."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    for s in (synth.resnet50_3x3(N=n)[2], synth.resnet50_3x3(N=n)[3]):
+        w = synth.pruned_weights(s, 31)
+        x = torch.rand((n, s.C, s.H, s.W), device=dev) * 2 - 1
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+        plan.weight_align(w)
+        assert _fast(plan.kernel_name), plan.kernel_name
+        got = plan.forward(x, None)
+        ref_plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_GENERIC)
+        ref_plan.weight_align(w)
+        ref = ref_plan.forward(x, None)
+        torch.cuda.synchronize()
+        scale = max(1e-6, float(ref.abs().max()))
+        assert float((got - ref).abs().max()) / scale <= TOL, (s.name, n, plan.tiling_info)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
+        want = oracle.conv_forward(g, x[n - 3:].cpu().numpy(), w, None, gate=False, threads=3)
+        assert rel_err(got[n - 3:].cpu().numpy(), want) <= TOL, (s.name, n)
+        plan.close(); ref_plan.close()

@@ -4,9 +4,9 @@
 // rocprofv3's FETCH_SIZE then shows 4-5x the algorithmic bytes for res5 / AlexNet conv3 (profiles/traffic_*.json).
 // FETCH_SIZE counts requests at the L2 / fabric interface (TCC_EA0_RDREQ); the Infinity Cache sits behind the fabric
 // and the TCC counters cannot tell a hit in it from a DRAM read (TCC_EA0_RDREQ_DRAM counts the requests' DESTINATION
-// type, DRAM vs GMI vs IO).  So this probe times it: 256 persistent workgroups stream a buffer
+// type, DRAM vs GMI vs IO).  So this probe times it: 2048 workgroups stream a buffer
 //   mode A "disjoint": every byte read by exactly one workgroup (one XCD)            -> B bytes through the L2s
-//   mode B "shared"  : the 32 workgroups of each XCD partition the WHOLE buffer       -> 8 B bytes through the L2s
+//   mode B "shared"  : the 256 workgroups of each XCD partition the WHOLE buffer      -> 8 B bytes through the L2s
 // HBM-cold: a ring of buffers larger than the 256 MiB Infinity Cache, one launch per buffer.  If mode B takes about as
 // long as mode A, seven of the eight reads of every line were served on-die (Infinity Cache) and the DRAM traffic of
 // such a layer is its algorithmic traffic, whatever FETCH_SIZE says; if it takes ~8x as long, they went to HBM.
@@ -16,6 +16,8 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+// 2048 workgroups (eight per CU: enough loads in flight to saturate the memory system -- a first version with one
+// 4-wave workgroup per CU was latency-bound at 2 TB/s and said nothing), eight independent 16-byte loads per lane
 __global__ void __launch_bounds__(256) stream_kernel(const float4 *__restrict__ buf, size_t n16, int shared, float *sink) {
   const int wg = blockIdx.x, nwg = gridDim.x;
   const int xcd = wg & 7, k = wg >> 3, per_xcd = nwg >> 3;
@@ -23,12 +25,22 @@ __global__ void __launch_bounds__(256) stream_kernel(const float4 *__restrict__ 
   const size_t parts = shared ? (size_t)per_xcd : (size_t)nwg;
   const size_t part = shared ? (size_t)k : (size_t)wg;
   const size_t lo = n16 * part / parts, hi = n16 * (part + 1) / parts;
-  float4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
-    const float4 v = buf[i];
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  float4 acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = float4{0.f, 0.f, 0.f, 0.f};
+  size_t i = lo + threadIdx.x;
+  for (; i + 7 * 256 < hi; i += 8 * 256) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = buf[i + (size_t)u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
   }
-  if (acc.x + acc.y + acc.z + acc.w == 123.456f) sink[wg] = acc.x + (float)xcd;     // (never: keeps the loads)
+  for (; i < hi; i += 256) { const float4 v = buf[i]; acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w; }
+  float t = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) t += acc[u].x + acc[u].y + acc[u].z + acc[u].w;
+  if (t == 123.456f) sink[wg & 1023] = t + (float)xcd;     // (never: keeps the loads)
 }
 
 int main() {
@@ -38,7 +50,7 @@ int main() {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  printf("256 workgroups x 256 lanes, 16-byte loads, ring of buffers > 256 MiB (every launch reads a buffer the Infinity Cache no longer holds)\n");
+  printf("2048 workgroups x 256 lanes, eight 16-byte loads in flight per lane, ring of buffers > 256 MiB (every launch reads a buffer the Infinity Cache no longer holds)\n");
   printf("%8s %6s | %12s %12s | %12s %12s | %s\n", "MB", "ring", "disjoint us", "GB/s", "shared us", "L2-side GB/s", "shared / disjoint time");
   for (size_t mb : sizes_mb) {
     const size_t bytes = mb << 20, n16 = bytes / 16;
@@ -50,12 +62,12 @@ int main() {
     }
     double t[2] = {0, 0};
     for (int shared = 0; shared < 2; ++shared) {
-      for (int i = 0; i < ring; ++i) hipLaunchKernelGGL(stream_kernel, dim3(256), dim3(256), 0, 0, bufs[i], n16, shared, sink);   // warm-up round
+      for (int i = 0; i < ring; ++i) hipLaunchKernelGGL(stream_kernel, dim3(2048), dim3(256), 0, 0, bufs[i], n16, shared, sink);   // warm-up round
       CHECK(hipDeviceSynchronize());
       const int rounds = 3;
       CHECK(hipEventRecord(e0));
       for (int r = 0; r < rounds; ++r)
-        for (int i = 0; i < ring; ++i) hipLaunchKernelGGL(stream_kernel, dim3(256), dim3(256), 0, 0, bufs[i], n16, shared, sink);
+        for (int i = 0; i < ring; ++i) hipLaunchKernelGGL(stream_kernel, dim3(2048), dim3(256), 0, 0, bufs[i], n16, shared, sink);
       CHECK(hipEventRecord(e1));
       CHECK(hipEventSynchronize(e1));
       float ms = 0;
