@@ -280,6 +280,43 @@ std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const
       ++recs[(size_t)m * nb + b];
     }
   auto count_of = [&](int o) { return std::max(0, std::min(G, Mg - o * G)); };
+  // Where the refinement below starts from.  Rounds 2-4 started from the channels' natural order and only ever
+  // swapped channels INSIDE a workgroup column: fine for uniformly pruned weights, not for a pruned model's -- a filter
+  // at four times the mean density next to all-zero ones (synth "filters_tail") left the slowest wave of a block 24 %
+  // over the mean on AlexNet's conv2 and the step 15 % slower than with uniform weights (profiles/r05_skew.md).
+  // So first a global deal: channels by descending total cost (rows touched and nonzeros over all blocks), each to
+  // the oc-group -- of ANY column -- with the least cost so far that still has a free slot (longest processing time
+  // first).  Heavy filters end up on different waves and different workgroups, empty ones fill the gaps.
+  // Deterministic (stable sort, first minimum).  ESCOIN_DEAL_LPT=0 (experiments flavour): the natural order.
+  static const bool lpt = (ESC_KNOB("DEAL_LPT", 1) != 0);
+  if (lpt) {
+    std::vector<double> cm(Mg, 0.0);
+    for (int m = 0; m < Mg; ++m) {
+      int rows = 0, rc = 0;
+      for (int b = 0; b < nb; ++b) {
+        const uint64_t *mk = &mask[((size_t)m * nb + b) * words];
+        for (int w = 0; w < words; ++w) rows += __builtin_popcountll(mk[w]);
+        rc += recs[(size_t)m * nb + b];
+      }
+      cm[m] = kGroupCost * rows + kRecordCost * rc;
+    }
+    std::vector<int> order(Mg);
+    for (int m = 0; m < Mg; ++m) order[m] = m;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cm[a] > cm[b]; });
+    std::vector<double> load(n_ocg, 0.0);
+    std::vector<int> fill(n_ocg, 0);
+    for (int m : order) {
+      int best = -1;
+      for (int o = 0; o < n_ocg; ++o)
+        if (fill[o] < count_of(o) && (best < 0 || load[o] < load[best])) best = o;
+      slot[(size_t)best * G + fill[best]] = (uint32_t)m;
+      ++fill[best];
+      load[best] += cm[m];
+    }
+    // (slots past a partly filled oc-group's last channel repeat a valid channel, as before)
+    for (int o = 0; o < n_ocg; ++o)
+      for (int gl = count_of(o); gl < G; ++gl) slot[(size_t)o * G + gl] = slot[(size_t)o * G + std::max(0, count_of(o) - 1)];
+  }
   // (one workgroup column at a time; the columns touch disjoint slots and run on threads of their own below)
   auto deal_column = [&](int blk0) {
   std::vector<uint64_t> acc(words);

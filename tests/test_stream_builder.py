@@ -43,8 +43,10 @@ def test_channel_deal_is_a_permutation_and_never_worse(tmp_path):
     text = out.stdout.decode()
     assert out.returncode == 0, text
     assert "all cases OK" in text
-    # ... and the tables are the ones the recompute-everything deal of rounds 2-4 produced (its incremental successor
-    # must take exactly the same swaps): seeded patterns, hashes of the slot -> channel tables
+    # ... and the tables are pinned: the deal is deterministic (seeded patterns, hashes of the slot -> channel tables).
+    # Round 5 changed where the refinement starts (a global longest-processing-time-first deal instead of the natural
+    # order: stream_builder.cpp), hence new hashes; the incremental cost update itself was pinned against the
+    # recompute-everything version in round 4.
     assert re.findall(r"table ([0-9a-f]{16})", text) == [
-        "a1ae34e0fa10ca7b", "fb941130f6083cb5", "c849f84ac359158b", "557a337c6eadb107", "31553581e755f76e", "1e0e07cf334fa7af",
-        "43eb030e59a267ff"]
+        "0f1fec86ccd5a1e5", "8cc9987d3bd9de89", "7dfc8de268d31c5d", "de43a4a92d53df97", "7e6a10f6a0edf747", "b73140c29c11e44f",
+        "1f054c7da250324f"]
