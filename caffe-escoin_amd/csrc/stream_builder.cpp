@@ -143,14 +143,29 @@ double launch_cost_us(const ConvGeom &g, const Tiling &t, int n_cu) {
 Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n_cu, bool one_tile_ok) {
   Tiling best = tile_with(g, waves_per_wg, lds_budget_bytes, 0, 0);
   if (!best.ok) return best;
-  double best_cost = launch_cost_us(g, best, n_cu);
+  // Generated code chains a tile's blocks only where every wave of every workgroup column has an oc-group
+  // (jit_codegen.h ChainPlan: n_ocg a multiple of oc_waves); a tiling that leaves a column's last waves without one
+  // falls back to a call per block and keeps those waves idle.  Measured on every candidate of the batch sweep's
+  // cliffs (tools/tiling_oracle.py, profiles/r05_batch_sweep.md): res4 with 5 columns of G = 7 (37 oc-groups) 160-170 us
+  // where 4 columns of G = 8 take 123-154; 6 and 7 columns 180-215.  The model prices such tilings a quarter up
+  // (one_tile_ok is what the caller passes for generated code).
+  auto cost_of = [&](const Tiling &t) {
+    return launch_cost_us(g, t, n_cu) * ((one_tile_ok && t.oc_waves > 1 && t.n_ocg % t.oc_waves != 0) ? 1.25 : 1.0);
+  };
+  // (experiments flavour: ESCOIN_FORCE_PASSES / ESCOIN_FORCE_NSEG pin the workgroup columns per conv group / the images per
+  //  tile, for sweeps of what the cost model could have chosen: tools/tiling_oracle.py)
+  if (ESC_KNOB_SET("FORCE_PASSES") || ESC_KNOB_SET("FORCE_NSEG")) {
+    const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, (int)ESC_KNOB("FORCE_PASSES", 0), (int)ESC_KNOB("FORCE_NSEG", 0));
+    if (t.ok && t.G >= 1) return t;
+  }
+  double best_cost = cost_of(best);
   const int base_passes = best.n_ocblk;
   const int fit = best.band_mode ? 1 : best.nseg;
   for (int passes = base_passes; passes <= 8 * base_passes; ++passes) {
     for (int nseg = fit; nseg >= 1; --nseg) {
       const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, passes, nseg);
       if (!t.ok || t.G < 1) continue;
-      const double c = launch_cost_us(g, t, n_cu);
+      const double c = cost_of(t);
       // more passes stage the input more often: only for a clear win; fewer images per tile at
       // the same number of passes cost nothing (fewer, larger blocks): any win counts
       if (c < best_cost * (passes > best.n_ocblk ? 0.97 : 0.999)) {
@@ -169,7 +184,7 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
     for (int passes = 1; passes < best.n_ocblk; ++passes) {
       const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, passes, best.nseg, 1);
       if (!t.ok || t.G < 1 || t.n_ocblk >= best.n_ocblk || t.band_mode || t.pix_waves != 1) continue;
-      const double c = launch_cost_us(g, t, n_cu);
+      const double c = cost_of(t);
       if (c < best_cost * 0.97) {
         best = t;
         best_cost = c;
