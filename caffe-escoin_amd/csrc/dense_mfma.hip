@@ -60,6 +60,7 @@ struct DenseArgs {
   int n_ptiles, n_mtiles, n_groups;        // tiles: pixel x channel x conv group (of this launch)
   unsigned in_bytes, w_bytes;              // buffer descriptor ranges
   int vec_out;                             // OH*OW % 4 == 0 and top 16-byte aligned: 16-byte stores through LDS
+  int s2_pair;                             // BMODE 2: a lane's two outputs come out of one aligned 16-byte quad (stride 2, even OW)
   unsigned long long group_mask;           // conv groups this launch covers (all ones: every group)
   int abl;                                 // ESCOIN_ABLATIONS builds: timing experiments (wrong results)
   // stream-K (STREAMK instantiations): every workgroup takes an equal, contiguous run of (tile, k-step) units;
@@ -101,8 +102,21 @@ __device__ __forceinline__ u32x4d make_rsrc(const void *p, unsigned bytes) {
 
 typedef unsigned __attribute__((address_space(1))) gu32;
 
-template <int WROWS, bool POINTWISE4, bool STREAMK = false>
+// BMODE: how the B tile (the im2col view) reaches LDS --
+//   0  gathered, 4 bytes per LDS-DMA lane (any kernel / stride / padding / dilation)
+//   1  pointwise (1x1, stride 1, no padding, H*W % 4 == 0): the column matrix IS the bottom blob, 16 bytes per DMA lane
+//   2  (experiments flavour only: measured slower than mode 0, see launch_dense)
+//      strided pointwise (1x1, stride > 1, no padding: ResNet-50's res{3,4,5}a_branch1 / branch2a): through registers.
+//      A lane owns two adjacent outputs of the tile; with stride 2 and an even output width their inputs are elements
+//      0 and 2 of ONE aligned 16-byte quad (a.s2_pair: one global_load_dwordx4 per k-row, the operand-side twin of
+//      the sparse path's strided view, sconv_tiled.hip TiledArgs::sub), otherwise two 4-byte loads; the two values go
+//      to LDS as one 8-byte write.  8 loads + 8 writes per wave and k-step where the gather issues 16 LDS-DMA
+//      instructions of 256 bytes -- an LDS-DMA instruction in a burst holds its wave ~100 cycles, and 16 of them were
+//      most of a k-step's 2048 MFMA cycles (profiles/r05_dense.md).
+template <int WROWS, int BMODE, bool STREAMK = false>
 __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) {
+  constexpr bool POINTWISE4 = BMODE == 1;
+  constexpr bool STRIDED1 = BMODE == 2;
   constexpr int BM = 64 * WROWS;
   constexpr int WCOLS = 4 / WROWS;           // waves along the pixel axis
   constexpr int WN = kBN / WCOLS;            // columns per wave: 64 or 32
@@ -147,9 +161,25 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
   unsigned fb_pix[2] = {0u, 0u};     // byte offset of the lane's pixel (window origin) in the blob
   int fb_ih0[2] = {0, 0}, fb_iw0[2] = {0, 0};
   int f_cg = 0, f_m0 = 0, f_p0 = 0;
+  // BMODE 2: element offsets (channel 0 of the conv group) of the lane's two outputs, the staging registers of the
+  // k-step in flight and where they go
+  size_t s_off[2] = {0, 0};
+  float4 s_q[STRIDED1 ? 8 : 1];
+  float s_d[STRIDED1 ? 16 : 1];
+  int s_k0 = 0, s_buf = 0;
+  bool s_pending = false;
   auto fetch_setup = [&](long tile) {
     tile_coords(tile, f_cg, f_m0, f_p0);
-    if (POINTWISE4) {
+    if (STRIDED1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        // (pairs: the lane's first output is even and the second its right neighbour, also in the tile's clamped tail)
+        const int p = a.s2_pair ? min(f_p0 + 2 * lane, a.P - 2) + e : min(f_p0 + 2 * lane + e, a.P - 1);
+        const int n = p / ohw, rem = p - n * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        s_off[e] = (((size_t)n * a.C + (size_t)f_cg * a.Cg) * a.H + (size_t)oh * a.stride_h) * a.W + (size_t)ow * a.stride_w;
+      }
+    } else if (POINTWISE4) {
       const int p = min(f_p0 + 4 * (lane & 31), a.P - 4);
       const int n = p / ohw, rem = p - n * ohw;
       fb_pix[0] = (unsigned)((((size_t)n * a.C + (size_t)f_cg * a.Cg + (lane >> 5)) * hw + rem) * 4);
@@ -174,7 +204,28 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
       const int i = wave + 4 * q;
       dma16(rA, ldsA + (unsigned)buf * kBufBytes + (unsigned)(i * 1024), voffA, sa + (unsigned)(i * 8 * a.lda * 4));
     }
-    if (POINTWISE4) {
+    if (STRIDED1) {
+      // this wave's 8 rows of the k-step into registers; rows past K are read from channel K - 1 and zeroed at the
+      // commit (a zero weight does not make NaNs harmless)
+      s_k0 = k0;
+      s_buf = buf;
+      s_pending = true;
+      if (a.s2_pair) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int kc = min(k0 + 8 * wave + r, a.K - 1);
+          s_q[r] = *reinterpret_cast<const float4 *>(a.in + s_off[0] + (size_t)kc * hw);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int kc = min(k0 + 8 * wave + r, a.K - 1);
+          s_d[2 * r] = a.in[s_off[0] + (size_t)kc * hw];
+          s_d[2 * r + 1] = a.in[s_off[1] + (size_t)kc * hw];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // (the loads stay here, ahead of the k-step's MFMAs)
+    } else if (POINTWISE4) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = wave + 4 * q;          // rows k0 + 2 i, k0 + 2 i + 1
@@ -207,6 +258,28 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
     }
   };
 
+  // BMODE 2: the staged k-step's values into its B tile (row k, columns 2 lane and 2 lane + 1: 512 consecutive bytes
+  // per row and wave, conflict-free); the barrier at the next k-step's top publishes them
+  auto commit = [&]() {
+    if (!STRIDED1 || !s_pending) return;
+    s_pending = false;
+    float *dst = &sAB[s_buf][BM * kBK];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = 8 * wave + r;
+      const bool live = s_k0 + row < a.K;
+      float2 v;
+      if (a.s2_pair) {
+        v.x = live ? s_q[r].x : 0.f;
+        v.y = live ? s_q[r].z : 0.f;
+      } else {
+        v.x = live ? s_d[2 * r] : 0.f;
+        v.y = live ? s_d[2 * r + 1] : 0.f;
+      }
+      *reinterpret_cast<float2 *>(&dst[row * kBN + 2 * lane]) = v;
+    }
+  };
+
   f32x16 acc[2][NB];
   // Work of this workgroup.  Tile mode: tiles blockIdx.x, + gridDim.x, ..., every k-step of each.  Stream-K:
   // units [u0, u1) of the (tile, k-step) sequence -- a run starts and ends anywhere in a tile.  The run's tiles are
@@ -227,6 +300,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
   if (!in_run(tile)) return;
   fetch_setup(tile);
   fetch(seg_lo(tile), 0);
+  commit();                       // (BMODE 2: the first step has no MFMAs to hide under)
   long f_tile = tile;             // tile of the step being fetched next
   int f_k = seg_lo(tile) + 1;     // ... and its k-step
   if (f_k == seg_hi(f_tile)) {
@@ -294,6 +368,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
           }
         }
       }
+      commit();       // (BMODE 2: the next step's B rows from the staging registers into the other buffer)
     }
     if (STREAMK) {
       // the lane's accumulators as 16 * NB quads: quad (i, j, r4) = acc[i][j][4 r4 .. 4 r4 + 3]
@@ -521,6 +596,20 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   const bool pointwise = g.d.KH == 1 && g.d.KW == 1 && g.d.stride_h == 1 && g.d.stride_w == 1 &&
                          g.d.pad_h == 0 && g.d.pad_w == 0;
   const bool vec_b = pointwise && (g.d.H * g.d.W) % 4 == 0 && (reinterpret_cast<uintptr_t>(bottom) & 15) == 0 && P >= 4;
+  // Strided pointwise layers (1x1, stride > 1, no padding) with the B tile staged through registers (kernel, BMODE 2: with
+  // stride 2, an even output width and 16-byte aligned rows a lane's two outputs are one aligned quad's elements 0 and
+  // 2) -- BUILT, MEASURED, NOT SHIPPED: same-call A/B on the ResNet-50 chain's six stride-2 layers at batch 256
+  // (profiles/r05_dense.md) 624-637 -> 642-678 us and 187-209 -> 188-228 us, i.e. 0-9 % SLOWER than the 4-byte LDS-DMA
+  // gather (parity green: tests/test_gpu_parity.py::test_dense_strided_pointwise_through_registers runs it in the
+  // experiments flavour).  Exists in the experiments flavour only, behind ESCOIN_DENSE_S2=1; the product gathers.
+#ifdef ESCOIN_EXPERIMENTS
+  static const bool s2_on = (ESC_KNOB("DENSE_S2", 0) != 0);
+#else
+  constexpr bool s2_on = false;
+#endif
+  const bool strided1 = s2_on && g.d.KH == 1 && g.d.KW == 1 && g.d.pad_h == 0 && g.d.pad_w == 0 && !pointwise && P >= 2;
+  a.s2_pair = strided1 && g.d.stride_w == 2 && g.OW % 2 == 0 && (g.d.H * g.d.W) % 4 == 0 && (g.d.stride_h * g.d.W) % 4 == 0 &&
+              (reinterpret_cast<uintptr_t>(bottom) & 15) == 0 ? 1 : 0;
   {
     static const bool vo = (ESC_KNOB("DENSE_VEC_OUT", 1) != 0);
     a.vec_out = vo && (g.OH * g.OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(top) & 15) == 0;
@@ -550,7 +639,7 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   //  with it, 3x3 layers have not been tried)
   const bool unit_1x1 = g.d.KH == 1 && g.d.KW == 1 && g.d.stride_h == 1 && g.d.stride_w == 1;
   bool streamk = sk_env >= 0 ? sk_env != 0 : (unit_1x1 && occupancy < 0.85 && nk >= 8 && tiles * nk >= 4 * slots);
-  if (tiles * nk < slots) streamk = false;
+  if (tiles * nk < slots || strided1) streamk = false;
   const long n_wg = streamk ? slots : std::min<long>(tiles, slots);
   a.sk_ws = nullptr;
   a.sk_flag = nullptr;
@@ -579,17 +668,23 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
     p->sk_flag_words = (int)n_wg + 1;
   }
   dim3 grid((unsigned)n_wg, 1, 1);
-#define ESC_DENSE_LAUNCH(WR, PW)                                                                                   \
+#define ESC_DENSE_LAUNCH(WR, MODE)                                                                                 \
   do {                                                                                                             \
-    if (streamk) hipLaunchKernelGGL((escoin_dense_mfma_kernel<WR, PW, true>), grid, dim3(256), 0, stream, a);       \
-    else hipLaunchKernelGGL((escoin_dense_mfma_kernel<WR, PW, false>), grid, dim3(256), 0, stream, a);             \
+    if (streamk) hipLaunchKernelGGL((escoin_dense_mfma_kernel<WR, MODE, true>), grid, dim3(256), 0, stream, a);     \
+    else hipLaunchKernelGGL((escoin_dense_mfma_kernel<WR, MODE, false>), grid, dim3(256), 0, stream, a);           \
   } while (0)
   if (bm == 64) {
-    if (vec_b) ESC_DENSE_LAUNCH(1, true);
-    else ESC_DENSE_LAUNCH(1, false);
+    if (vec_b) ESC_DENSE_LAUNCH(1, 1);
+#ifdef ESCOIN_EXPERIMENTS
+    else if (strided1) hipLaunchKernelGGL((escoin_dense_mfma_kernel<1, 2, false>), grid, dim3(256), 0, stream, a);
+#endif
+    else ESC_DENSE_LAUNCH(1, 0);
   } else {
-    if (vec_b) ESC_DENSE_LAUNCH(2, true);
-    else ESC_DENSE_LAUNCH(2, false);
+    if (vec_b) ESC_DENSE_LAUNCH(2, 1);
+#ifdef ESCOIN_EXPERIMENTS
+    else if (strided1) hipLaunchKernelGGL((escoin_dense_mfma_kernel<2, 2, false>), grid, dim3(256), 0, stream, a);
+#endif
+    else ESC_DENSE_LAUNCH(2, 0);
   }
 #undef ESC_DENSE_LAUNCH
   ESCOIN_HIP_TRY(hipGetLastError());
