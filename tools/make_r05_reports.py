@@ -197,6 +197,52 @@ def skew():
         f.write(notes("r05_skew"))
 
 
+def batch_sweep():
+    after, before, oracle = G("r05h", "batch_sweep_line.md"), G("r05b", "batch_sweep_line.md"), G("r05g", "tiling_oracle.txt")
+    if not os.path.exists(after):
+        return
+
+    def quant(table):
+        """Adds, per cell, what whole tiles on whole workgroups cost: rounds needed / rounds an ideal split would need."""
+        out = []
+        for line in table.splitlines():
+            if not line.startswith("| ") or line.startswith("| layer") or line.startswith("|---"):
+                out.append(line)
+                continue
+            cells = line.split(" | ")
+            new = [cells[0]]
+            for c in cells[1:]:
+                m = re.search(r"\[(\d+)x(\d+) t, (\d+) col\]", c)
+                if m:
+                    tiles, cols = int(m.group(2)), int(m.group(3))
+                    gx = max(1, 256 // cols)
+                    rounds = -(-tiles // gx)
+                    c = c.rstrip(" |") + " q=%.2f" % (tiles / float(gx) / rounds)
+                new.append(c)
+            out.append(" | ".join(new) + (" |" if not new[-1].rstrip().endswith("|") else ""))
+        return "\n".join(out)
+
+    with open(P("r05_batch_sweep.md"), "w") as f:
+        f.write("# Batches the tilings were not tuned for (r05, one MI355X)\n\n"
+                "`python tools/batch_sweep.py --batches 96,100,192,200,250,255,257,293,300,341,384,512 <layers>`: every plan created for ITS batch, HBM-cold\n"
+                "(rotating bottom / top pairs), 40 launches, best of three.  Cell = `us (images/s relative to the straight line through this run's N = 128 and N = 256\n"
+                "points) [images per tile x tiles, workgroup columns] q = tiles / (workgroups per column x rounds)` -- q is what whole tiles on whole\n"
+                "workgroups can deliver at best: q = 0.67 means the last of three rounds is one tile wide.\n\n"
+                "## After round 5's change to the tiling cost model (tilings that cannot chain are priced a quarter up)\n\n")
+        f.write(quant(open(after).read().split("\n\n", 1)[1] if "\n\n" in open(after).read() else open(after).read()) + "\n\n")
+        if os.path.exists(before):
+            f.write("## Before (round 4's model, `gpurun_out/r05b`)\n\n")
+            f.write(quant(open(before).read().split("\n\n", 1)[1]) + "\n\n")
+        if os.path.exists(oracle):
+            f.write("## What the model could have chosen (`tools/tiling_oracle.py`, experiments flavour: every workgroup-column count x images per tile forced; round 4's model as AUTO)\n\n```\n")
+            keep = []
+            for line in open(oracle):
+                if " AUTO: " in line or "better than AUTO" in line:
+                    keep.append(line.rstrip())
+            f.write("\n".join(keep) + "\n```\n")
+        f.write(notes("r05_batch_sweep"))
+
+
 def copy_files():
     for src, dst in ((G("r05b", "bench_resnet50_1rank_rccl.json"), P("r05_bench_resnet50_1rank_rccl.json")),
                      (G("r05b", "rccl_selfcheck.txt"), P("r05_rccl_selfcheck.txt"))):
@@ -209,5 +255,6 @@ if __name__ == "__main__":
     half_workgroups()
     small_launch()
     skew()
+    batch_sweep()
     copy_files()
     print("written:", sorted(os.path.basename(p) for p in glob.glob(P("r05_*"))))

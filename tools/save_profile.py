@@ -45,7 +45,7 @@ def main():
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                             r["Percentage"], r["MinNs"], r["MaxNs"]])
     out = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_ea"):
         for fn in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
             for r in csv.DictReader(open(fn)):
                 k = short(r["Kernel_Name"])
