@@ -108,6 +108,34 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     enc_v_add_u32_s(c, kVTabAddr, kSTabDelta, kVTabAddr);
   }
   const int n = (opt.ablate & 8) ? 0 : (int)rows.size();
+  // Weights through the scalar cache (Options::sweights): which line and slot every nonzero of the unit's walk takes.
+  // A line ends where the next ROW would not fit (so that the switch to a line sits at a row top, where the wave waits
+  // for LDS anyway); a row of more than 16 nonzeros runs over several lines.
+  const bool sw = opt.sweights && !opt.ablate;
+  std::vector<int> line_of, slot_of;
+  int n_lines = 0;
+  size_t sw_patch = 0;          // index (in `c`) of the literal that carries the distance to the unit's weight lines
+  size_t sw_from = 0;           // byte address (in `c`) s_getpc_b64 returns
+  if (sw) {
+    int fill = kSWLine;         // (forces a new line at the first nonzero)
+    for (int k = 0; k < n; ++k) {
+      const int rn = (int)rows[k].recs.size();
+      if (fill + rn > kSWLine && rn <= kSWLine && fill > 0) fill = kSWLine;     // the row starts a new line
+      for (int r = 0; r < rn; ++r) {
+        if (fill == kSWLine) { ++n_lines; fill = 0; }
+        line_of.push_back(n_lines - 1);
+        slot_of.push_back(fill++);
+      }
+    }
+    if (n_lines > 0) {
+      enc_getpc(c, kSWBase);
+      sw_from = c.size() * 4;
+      sw_patch = c.size() + 1;
+      enc_s_add_lit(c, kSWBase, 0u);           // + (first weight line - that address): patched below
+      enc_s_addc(c, kSWBase + 1, false);
+      enc_s_load_x16(c, kSWBuf0, kSWBase, 0u);
+    }
+  }
   // Without a tile B the 24 input registers hold SIX quads instead of three pairs: rows are read five
   // ahead.  A row of such a layer (pointwise, 95 % sparse) carries one or two nonzeros -- 10-25 cycles of
   // FMAs -- and an LDS read takes well over a hundred to land: two rows of read-ahead left the walk
@@ -184,7 +212,7 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
   }
   first_of_row[n] = (int)flat.size();
   auto sreg = [](int j) { return (j & 1) ? kSWeight1 : kSWeight0; };
-  if (opt.hoist_weight && !flat.empty() && !(opt.ablate & 4)) enc_s_mov_lit(c, sreg(0), flat[0]->bits);
+  if (!sw && opt.hoist_weight && !flat.empty() && !(opt.ablate & 4)) enc_s_mov_lit(c, sreg(0), flat[0]->bits);
   if ((opt.ablate & 4) && (opt.ablate & 16384)) {
     // no weight moves, but two nonzero weights in the registers: the FMAs do real arithmetic.  (With whatever the
     // registers held -- zeros -- the chip draws less power and clocks higher: bit 2 alone overstates the moves' cost
@@ -193,8 +221,18 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     enc_s_mov_lit(c, kSWeight1, 0xBF4A7B2Du);
   }
   int prio = 0;
+  // (sweights) the switch to weight line L: everything outstanding lands -- the line, loaded a line ago, and the LDS
+  // reads in flight --, then the line after it is requested into the other buffer
+  auto switch_line = [&](int L) {
+    enc_waitcnt_lgkm(c, 0);
+    lds.done = lds.issued;
+    if (L + 1 < n_lines) enc_s_load_x16(c, ((L + 1) & 1) ? kSWBuf1 : kSWBuf0, kSWBase, (uint32_t)(L + 1) * 64u);
+  };
   for (int k = 0; k < n; ++k) {
     read_tables(k);
+    const int j0 = first_of_row[k];
+    const bool row_switches = sw && j0 < first_of_row[k + 1] && slot_of[j0] == 0;
+    if (row_switches) switch_line(line_of[j0]);       // in FRONT of the read-ahead: the wait then covers reads a row old
     if (k + depth < n) issue(k + depth);
     if (opt.prio_rows > 0 && k % opt.prio_rows == 0) {
       prio ^= 1;
@@ -205,7 +243,9 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     issue_pieces(k);
     const int xa = set_base(k), xb = xa + 4;
     for (int j = first_of_row[k]; j < first_of_row[k + 1]; ++j) {
-      if (opt.ablate & 4) {
+      if (sw) {
+        if (j > j0 && slot_of[j] == 0) switch_line(line_of[j]);     // (a row of more than 16 nonzeros)
+      } else if (opt.ablate & 4) {
       } else if (opt.hoist_weight) {
         if (j + 1 < (int)flat.size()) enc_s_mov_lit(c, sreg(j + 1), flat[j + 1]->bits);
       } else {
@@ -215,6 +255,12 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
       const int a = 4 * flat[j]->idx;
       // (timing only: 512 = an s_nop behind every FMA -- four more instructions and 16 more bytes per nonzero)
       auto fma = [&](int acc, int x) {
+        if (sw) {
+          const int pair = ((line_of[j] & 1) ? kSWBuf1 : kSWBuf0) + (slot_of[j] & ~1);
+          if (slot_of[j] & 1) enc_pk_fma_hi(c, acc, pair, x);
+          else enc_pk_fma(c, acc, pair, x);
+          return;
+        }
         enc_pk_fma(c, acc, sreg(j), x);
         if (opt.ablate & 512) enc_nop(c);
       };
@@ -249,10 +295,26 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     enc_s_add_u32_lit(c, kSFillBase, kSFillBase, opt.chain.buf_bytes);
     enc_s_cmp_lt_u32_lit(c, kSFillBase, all);
     enc_s_cselect_or_zero(c, kSFillBase, kSFillBase);
-    return patch;       // (the next unit follows: alignment padding is s_nop)
+    if (sw && n_lines > 0) {
+      // over the weight lines into the next unit (which starts on the 64-byte boundary behind them)
+      const size_t at = c.size();
+      enc_s_branch(c, 0);
+      while ((c.size() * 4) % 64) enc_nop(c);
+      c[at] = 0xBF820000u | (uint32_t)((c.size() - at - 1 + (size_t)n_lines * 16) & 0xFFFFu);
+    }
+  } else {
+    enc_setpc_return(c);
   }
-  enc_setpc_return(c);
-  return patch;
+  if (sw && n_lines > 0) {
+    // the unit's weight lines: 16 per 64-byte line in walk order, zero padded; never executed
+    while ((c.size() * 4) % 64) enc_nop(c);
+    const long long dist = (long long)(c.size() * 4) - (long long)sw_from;
+    c[sw_patch] = (uint32_t)dist;
+    std::vector<uint32_t> lines((size_t)n_lines * kSWLine, 0u);
+    for (size_t j = 0; j < flat.size(); ++j) lines[(size_t)line_of[j] * kSWLine + slot_of[j]] = flat[j]->bits;
+    c.insert(c.end(), lines.begin(), lines.end());
+  }
+  return patch;       // (chained: the next unit follows; alignment padding is s_nop)
 }
 
 }  // namespace

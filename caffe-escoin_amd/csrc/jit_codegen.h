@@ -144,6 +144,23 @@ inline void enc_v_add_u32_s(std::vector<uint32_t> &c, int vdst, int ssrc, int vs
   c.push_back(0x68000000u | ((uint32_t)vdst << 17) | ((uint32_t)vsrc << 9) | (uint32_t)ssrc);
 }
 inline void enc_setprio(std::vector<uint32_t> &c, int p) { c.push_back(0xBF8F0000u | (uint32_t)(p & 3)); }
+// ---- weights through the scalar data cache (Options::sweights below) ----
+// v_pk_fma_f32 v[acc:acc+1], s[sw:sw+1], v[x:x+1], v[acc:acc+1] op_sel:[1,0,0] op_sel_hi:[1,1,1]
+// (both halves multiply by the HIGH dword of the SGPR pair)
+inline void enc_pk_fma_hi(std::vector<uint32_t> &c, int acc, int sw, int x) {
+  c.push_back(0xD3B04800u | (uint32_t)acc);
+  c.push_back((uint32_t)sw | ((256u + (uint32_t)x) << 9) | ((256u + (uint32_t)acc) << 18) | (3u << 27));
+}
+// s_load_dwordx16 s[sd:sd+15], s[sbase:sbase+1], <imm offset (bytes, 21 bits)>
+inline void enc_s_load_x16(std::vector<uint32_t> &c, int sd, int sbase, uint32_t off) {
+  c.push_back(0xC0120000u | ((uint32_t)sd << 6) | ((uint32_t)sbase >> 1));
+  c.push_back(off & 0x1FFFFFu);
+}
+// s_branch <simm16 dwords, relative to the next instruction>
+inline void enc_s_branch(std::vector<uint32_t> &c, int dwords) { c.push_back(0xBF820000u | ((uint32_t)dwords & 0xFFFFu)); }
+constexpr int kSWBuf0 = 56, kSWBuf1 = 72;   // two buffers of 16 weights: s[56:71], s[72:87]
+constexpr int kSWBase = 88;                 // s[88:89]: address of the unit's weight lines
+constexpr int kSWLine = 16;                 // weights per line (one s_load_dwordx16, 64 bytes)
 inline void enc_nop(std::vector<uint32_t> &c) { c.push_back(0xBF800000u); }
 
 // What the generated code must know to stage the next block's planes itself.
@@ -210,6 +227,14 @@ struct Options {
   DmaPlan dma;
   ChainPlan chain;
   int prefetch = 1;       // touch the next unit's code (above)
+  int sweights = 0;       // 1: no literal move per nonzero -- a unit's weights lie in 64-byte lines behind its code (an island the
+                          // chain branches over), one s_load_dwordx16 per 16 nonzeros brings a line into one of two SGPR
+                          // buffers a line ahead of use, and the FMAs read their weight from the buffer (low or high half of a
+                          // pair).  Scalar loads return out of order with LDS reads (one counter): the switch to a line is an
+                          // s_waitcnt lgkmcnt(0), placed in front of the row's read-ahead; the counted LDS waits ignore the
+                          // load in flight, which can only make them wait longer.  4.06 instead of 5 instructions and 36 instead
+                          // of 40 code bytes per nonzero; for the 3x3 / 5x5 layers (their kernel instantiation pays 34 more
+                          // clobbered SGPRs around the call: sconv_tiled.hip)
   int one_tile = 0;       // set by build_program: the tiling leaves tile B without rows, its reads and FMAs
                           // are not generated (-1: never, ESCOIN_JIT_ONE_TILE=0)
 };

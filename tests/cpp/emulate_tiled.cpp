@@ -58,6 +58,7 @@ struct JitChainCtx {
   std::vector<size_t> unit_end;            // pc just past each unit's last instruction
 };
 
+static long g_weight_lines = 0;      // s_load_dwordx16 executed (Options::sweights)
 static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w, const std::vector<float> &lds,
                         const std::vector<uint32_t> &laneA /* LDS byte address of the lane's tile-A quad */,
                         JitDmaCtx *dma = nullptr, JitPref *pref = nullptr, JitChainCtx *chain = nullptr) {
@@ -71,6 +72,9 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
   uint32_t sreg[128] = {0};
   uint32_t m0 = 0;
   unsigned long long exec = ~0ull;
+  bool sw_base_set = false;             // s[88:89] hold this unit's weight-line address
+  bool smem_pending[2] = {false, false};   // a line is on its way into s[56:71] / s[72:87]: lands at the next lgkmcnt(0)
+  uint32_t smem_data[2][16];
   bool tab_unissued[256] = {false};     // a table entry was read into this register and its piece has not gone out
   if (dma) sreg[48] = dma->fill_base;
   if (chain) {
@@ -109,6 +113,29 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       return 0;
     }
     if (d0 == 0xBEFE01C1u) { exec = ~0ull; pc += 4; continue; }   // s_mov_b64 exec, -1
+    // ---- weights through the scalar cache (jit_codegen.h Options::sweights) ----
+    if (d0 == (0xBE801C00u | (88u << 16))) { sreg[88] = (uint32_t)(pc + 4); sreg[89] = 0; sw_base_set = true; pc += 4; continue; }   // s_getpc_b64 s[88:89]
+    if (d0 == 0x82598059u) { pc += 4; continue; }                  // s_addc_u32 s89, s89, 0
+    if ((d0 & 0xFFFFE03Fu) == (0xC0120000u | 44u)) {               // s_load_dwordx16 s[sd:sd+15], s[88:89], imm
+      const int sd = (int)((d0 >> 6) & 0x7F);
+      const uint32_t off = code[pc / 4 + 1];
+      if (!sw_base_set || (sd != 56 && sd != 72) || (off & 63)) { printf("jit: bad s_load_dwordx16 (sd %d, offset %u)\n", sd, off); return 3; }
+      const size_t at = ((size_t)sreg[88] + off) / 4;
+      if (((size_t)sreg[88] + off) % 64 || at + 16 > code.size()) { printf("jit: weight line at %zu is not a 64-byte line of the blob\n", at * 4); return 3; }
+      if (smem_pending[sd == 56 ? 0 : 1]) { printf("jit: weight buffer s%d loaded twice without a wait\n", sd); return 3; }
+      smem_pending[sd == 56 ? 0 : 1] = true;
+      ++g_weight_lines;
+      for (int e = 0; e < 16; ++e) smem_data[sd == 56 ? 0 : 1][e] = code[at + e];
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFFFF0000u) == 0xBF820000u) {                       // s_branch: over a unit's weight lines into the next unit
+      const int simm = (int16_t)(d0 & 0xFFFFu);
+      if (!chain || simm <= 0) { printf("jit: unexpected s_branch %d\n", simm); return 3; }
+      pc += 4 + 4 * (size_t)simm;
+      if (pc % 64) { printf("jit: s_branch lands off a unit's 64-byte boundary\n"); return 3; }
+      continue;
+    }
     if (d0 == 0xBEB21C00u) { s50 = (long long)pc + 4; pc += 4; continue; }   // s_getpc_b64 s[50:51]
     if (d0 == 0x8032FF32u) { s50 += (long long)(int32_t)code[pc / 4 + 1]; pc += 8; continue; }   // s_add_u32 s50, s50, lit (+ the carry below)
     if (d0 == 0x82338033u || d0 == 0x8233C133u) {   // s_addc_u32 s51, s51, 0 | -1: the sign of the literal just added
@@ -188,6 +215,12 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
     if ((d0 & 0xFFFF0000u) == 0xBF8C0000u) {   // s_waitcnt lgkmcnt(n)
       if ((d0 & 0xF0FFu) != 0xC07Fu) { printf("jit: unexpected s_waitcnt fields\n"); return 3; }
       retire_to((d0 >> 8) & 15);
+      if (((d0 >> 8) & 15) == 0)          // (scalar loads return out of order with LDS reads: only a wait for everything settles them)
+        for (int b = 0; b < 2; ++b)
+          if (smem_pending[b]) {
+            smem_pending[b] = false;
+            for (int e = 0; e < 16; ++e) sreg[(b ? 72 : 56) + e] = smem_data[b][e];
+          }
       pc += 4;
       continue;
     }
@@ -285,13 +318,16 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       pc += 8;
       continue;
     }
-    if ((d0 & 0xFFFFFF00u) == 0xD3B04000u) {   // v_pk_fma_f32 acc, s[w:w+1], v[x:x+1], acc op_sel_hi:[0,1,1]
+    if ((d0 & 0xFFFFF700u) == 0xD3B04000u) {   // v_pk_fma_f32 acc, s[w:w+1], v[x:x+1], acc op_sel_hi:[0,1,1] | op_sel:[1,0,0] op_sel_hi:[1,1,1]
       const int acc = (int)(d0 & 0xFF), sw = (int)(d1 & 0x1FF);
+      const int hi = (d0 >> 11) & 1;        // the weight is the pair's high dword
       const int x = (int)((d1 >> 9) & 0x1FF) - 256, acc2 = (int)((d1 >> 18) & 0x1FF) - 256;
-      if (acc != acc2 || acc < 64 || acc > 254 || (acc & 1) || x < 36 || (x > 58 && (x < 160 || x > 254 || acc >= 160)) || sw > 101 || (d1 >> 27) != 2u) { printf("jit: bad v_pk_fma_f32 operands\n"); return 3; }
+      if (acc != acc2 || acc < 64 || acc > 254 || (acc & 1) || x < 36 || (x > 58 && (x < 160 || x > 254 || acc >= 160)) || sw > 101 || (sw & 1) ||
+          (d1 >> 27) != (hi ? 3u : 2u) || (hi && sw < 56)) { printf("jit: bad v_pk_fma_f32 operands\n"); return 3; }
       if (is_pending(x) || is_pending(x + 1)) { printf("jit: FMA reads v%d before its LDS read was waited for\n", x); return 3; }
+      if (sw >= 56 && sw < 88 && smem_pending[sw >= 72 ? 1 : 0]) { printf("jit: FMA reads weight buffer s%d before its line was waited for\n", sw); return 3; }
       float wv;
-      std::memcpy(&wv, &sreg[sw], 4);
+      std::memcpy(&wv, &sreg[sw + hi], 4);
       for (int lane = 0; lane < 64; ++lane) {
         float *V = &w.v[(size_t)lane * 256];
         V[acc] = std::fmaf(wv, V[x], V[acc]);
@@ -344,6 +380,7 @@ static int run(const Case &cs, bool use_jit) {
     jo.prio_rows = (cs.M & 1) ? 2 : 0;
     jo.hi_sets = (cs.N & 1) ? 24 : 0;     // (used only by code without a tile B: deeper read-ahead through tile B's registers)
     jo.depth_one_tile = (cs.N & 1) ? 5 + cs.N % 9 : 5;
+    jo.sweights = cs.KW != 1 && (cs.C & 3) != 1;     // weights through the scalar cache: most 3x3 / 5x5 geometries (not all: both forms stay covered)
     // plane DMA from inside the code wherever one wave owns an oc-group (whatever the table's size: the
     // product bounds it, the emulation does not need to)
     if (t.pix_waves == 1 && (t.waves == 8 || t.waves == 4)) {
@@ -713,10 +750,11 @@ static int run(const Case &cs, bool use_jit) {
   }
   const double rel = maxerr / std::fmax(1e-6, maxref);
   printf("%s%sN%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: tpl=%d S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
-         "groups=%ld recs=%ld recs/group=%.2f dma=%ld rel_err=%.2e\n",
+         "groups=%ld recs=%ld recs/group=%.2f dma=%ld lines=%ld rel_err=%.2e\n",
          use_jit ? "jit " : "", use_jit && jp.chained ? "chained " : "", cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.tpl, t.S4, t.G,
          t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes,
-         ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, dma_checked, rel);
+         ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, dma_checked, g_weight_lines, rel);
+  g_weight_lines = 0;
   if (use_jit && jdma.on && dma_checked == 0) { printf("jit dma: nothing was checked\n"); return 3; }
   return rel <= 1e-5 ? 0 : 1;
 }

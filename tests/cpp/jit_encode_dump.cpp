@@ -51,6 +51,43 @@ int main() {
              sd + 1, x, x + 1, acc, acc + 1);
     dump(buf, c);
   }
+  // weights through the scalar cache (Options::sweights)
+  for (int i = 0; i < 60; ++i) {
+    std::vector<uint32_t> c;
+    const int acc = 64 + 2 * rnd(96), x = 36 + 2 * rnd(12), pair = ((i & 1) ? kSWBuf1 : kSWBuf0) + 2 * rnd(8);
+    enc_pk_fma_hi(c, acc, pair, x);
+    snprintf(buf, sizeof buf, "v_pk_fma_f32 v[%d:%d], s[%d:%d], v[%d:%d], v[%d:%d] op_sel:[1,0,0] op_sel_hi:[1,1,1]", acc, acc + 1, pair, pair + 1, x, x + 1,
+             acc, acc + 1);
+    dump(buf, c);
+    c.clear();
+    enc_pk_fma(c, acc, pair, x);
+    snprintf(buf, sizeof buf, "v_pk_fma_f32 v[%d:%d], s[%d:%d], v[%d:%d], v[%d:%d] op_sel_hi:[0,1,1]", acc, acc + 1, pair, pair + 1, x, x + 1, acc, acc + 1);
+    dump(buf, c);
+    c.clear();
+    const int sd = (i & 1) ? kSWBuf1 : kSWBuf0;
+    const unsigned off = 64 * rnd(16000);
+    enc_s_load_x16(c, sd, kSWBase, off);
+    snprintf(buf, sizeof buf, "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x%x", sd, sd + 15, kSWBase, kSWBase + 1, off);
+    dump(buf, c);
+    c.clear();
+    const int dw = 1 + (int)rnd(30000);
+    enc_s_branch(c, dw);
+    snprintf(buf, sizeof buf, "s_branch %d", dw);
+    dump(buf, c);
+    c.clear();
+    enc_getpc(c, kSWBase);
+    snprintf(buf, sizeof buf, "s_getpc_b64 s[%d:%d]", kSWBase, kSWBase + 1);
+    dump(buf, c);
+    c.clear();
+    const uint32_t lit = 0x100u + 64u * rnd(100000);
+    enc_s_add_lit(c, kSWBase, lit);
+    snprintf(buf, sizeof buf, "s_add_u32 s%d, s%d, 0x%x", kSWBase, kSWBase, lit);
+    dump(buf, c);
+    c.clear();
+    enc_s_addc(c, kSWBase + 1, false);
+    snprintf(buf, sizeof buf, "s_addc_u32 s%d, s%d, 0", kSWBase + 1, kSWBase + 1);
+    dump(buf, c);
+  }
   for (int i = 0; i < 40; ++i) {
     std::vector<uint32_t> c;
     const int vd = (i & 1) ? kVTab1 + (int)rnd(2) : kVTab0;
