@@ -111,7 +111,7 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
   // Weights through the scalar cache (Options::sweights): which line and slot every nonzero of the unit's walk takes.
   // A line ends where the next ROW would not fit (so that the switch to a line sits at a row top, where the wave waits
   // for LDS anyway); a row of more than 16 nonzeros runs over several lines.
-  const bool sw = opt.sweights && !opt.ablate;
+  bool sw = opt.sweights && !opt.ablate;
   std::vector<int> line_of, slot_of;
   int n_lines = 0;
   size_t sw_patch = 0;          // index (in `c`) of the literal that carries the distance to the unit's weight lines
@@ -126,6 +126,14 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
         line_of.push_back(n_lines - 1);
         slot_of.push_back(fill++);
       }
+    }
+    if ((size_t)n_lines * kSWLine > 30000) {
+      // (the branch over the lines has a 16-bit word offset: a unit of more than ~30 000 nonzeros -- a whole layer of tiny
+      //  images in one block -- keeps the literal moves; units of both kinds may follow each other)
+      sw = false;
+      n_lines = 0;
+      line_of.clear();
+      slot_of.clear();
     }
     if (n_lines > 0) {
       enc_getpc(c, kSWBase);

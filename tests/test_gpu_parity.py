@@ -1239,3 +1239,35 @@ def test_dense_strided_pointwise_through_registers(pkg, oracle, synth, torch_cud
             plan.close()
             assert np.isfinite(got).all(), s.name
             assert rel_err(got, want) <= TOL, "%s relu=%d: %g" % (s.name, relu, rel_err(got, want))
+
+
+def test_half_workgroups_on_hbm_bound_pointwise_layers(pkg, oracle, synth, torch_cuda):
+    """Two 4-wave workgroups per CU (sconv_tiled.hip, half-workgroup rule): what KERNEL_AUTO tiles GoogLeNet's 28 x 28 1x1 layers
+    with up to 96 output channels as at batch 256.  The tiling of batch 256 on small inputs (tiling_batch), output channel
+    counts that do and do not fill the four waves, bias, fused ReLU, a partial batch, and the cases the rule must NOT take
+    (128 channels; 14 x 14: one tile per workgroup; 56 x 56: seven)."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    taken = 0
+    for k, (C, HW, M, expect) in enumerate([(192, 28, 64, True), (192, 28, 96, True), (192, 28, 16, True), (192, 28, 20, True),
+                                            (256, 28, 32, True), (256, 28, 90, True), (256, 28, 128, False), (480, 14, 64, False),
+                                            (64, 56, 64, False)]):
+        s = synth.shape("half_wg", 5, C, HW, HW, M, 1, bias=True, sparsity=0.95)
+        w, b, x = synth.pruned_weights(s, 900 + k), synth.bias_vector(s, 920 + k), synth.activations(s, 940 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, 1, 1, 0, 0)
+        for relu in (False, True):
+            want = oracle.conv_forward(g, x, w, b, relu=relu, gate=False, threads=4)
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s, fuse_relu=relu), tiling_batch=256)
+            plan.weight_align(w)
+            half = "oc_waves=4 pix_waves=1" in plan.tiling_info
+            assert half == expect, (C, HW, M, plan.tiling_info)
+            taken += half
+            xd, bd = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
+            got = plan.forward(xd, bd).cpu().numpy()
+            assert rel_err(got, want) <= TOL, (C, HW, M, relu, rel_err(got, want))
+            # a partial batch through the same plan
+            top = torch.full((3, s.M, HW, HW), float("nan"), device=dev)
+            plan.forward(xd[:3].contiguous(), bd, top)
+            assert rel_err(top.cpu().numpy(), want[:3]) <= TOL
+            plan.close()
+    assert taken == 12
