@@ -187,7 +187,11 @@ ESCOIN_API int escoin_plan_import_aligned(escoin_plan *plan, const void *buf, si
  * "kernel_choice" (the ESCOIN_KERNEL_* id AUTO resolved to for the sparse groups), "small_launch_rule" (KERNEL_AUTO's
  * rule for pointwise launches under 64 MFLOP that fit one round of workgroups -- the reference's SCONV mode runs
  * image by image, conv_layer.cu:16-26 --: 0 not considered, 1 kept generated code, 2 took the generic kernel; a
- * function of the options, the weights and the batch only: the same in every process), "streamk" / "streamk_gave_up"
+ * function of the options, the weights and the batch only: the same in every process),
+ * "deal_slowest_over_mean_x1000" / "deal_worst_block_x1000" (generated-code plans aligned from weights: how evenly
+ * WeightAlign dealt the output channels over the waves that meet at a block's barrier -- slowest wave / mean wave,
+ * weighted over all blocks, and the worst single block, x 1000; 0 for a plan restored from a persisted code object),
+ * "streamk" / "streamk_gave_up"
  * (dense kernel; a give-up also makes the next escoin_forward on the plan fail with ESCOIN_EHIP). */
 ESCOIN_API long escoin_plan_stat(const escoin_plan *plan, const char *key);
 
