@@ -24,9 +24,14 @@ int oracle_out_dim(int in, int k, int pad, int stride, int dil) {
 }
 
 long oracle_padded_len(const oracle_conv_geom *g) {
-  /* base_conv_layer.cpp:71 */
+  /* base_conv_layer.cpp:71 -- rows are W + pad_w long (a row's right padding is the next row's left padding), channels
+   * H + pad_h rows (likewise), and the slack behind the last channel is pad_h * (W + 2 pad_w) floats.  That covers the
+   * last row's right padding only when pad_h >= 1: with pad_h == 0 < pad_w the reference's kernels read pad_w floats
+   * PAST its allocation at the last output columns of the last channel's last row (undefined there; none of its models
+   * has such a layer).  The oracle defines those reads as the zero padding the layer specifies: pad_w floats more,
+   * zero like the rest (found by tools/fuzz_parity.py: every GPU kernel agreed with each other and not with the oracle). */
   return (long)g->C * (g->H + g->pad_h) * (g->W + g->pad_w) +
-         (long)g->pad_h * (g->W + 2 * g->pad_w);
+         (long)g->pad_h * (g->W + 2 * g->pad_w) + (g->pad_h == 0 ? g->pad_w : 0);
 }
 
 int oracle_dense2csr(int M, int N, const float *A, float *values, int *colidx,

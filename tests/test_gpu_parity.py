@@ -785,6 +785,38 @@ def test_stream_stores_option_changes_nothing_but_the_store_instruction(pkg, ora
         assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3]), s.name
 
 
+def test_padding_in_one_direction_only(pkg, oracle, synth, torch_cuda):
+    """pad_h == 0 < pad_w (and the reverse), where the reference's padded buffer ends short of its own reads
+    (oracle/sconv_oracle.c oracle_padded_len): every kernel family pads with zeros, the generic one bit for bit."""
+    for k, (KH, KW, ph, pw, st) in enumerate([(3, 3, 0, 2, 1), (1, 5, 0, 4, 1), (7, 7, 0, 6, 1), (2, 5, 0, 4, 2), (4, 4, 0, 3, 1),
+                                              (3, 3, 2, 0, 1), (5, 1, 3, 0, 1), (1, 3, 0, 2, 3)]):
+        s = synth.shape("p1_%d" % k, 5, 12, 9, 23, 20, KH, KW=KW, pad=ph, pad_w=pw, stride=st, sparsity=0.8)
+        w, b, x = synth.pruned_weights(s, 7100 + k), synth.bias_vector(s, 7200 + k), synth.activations(s, 7300 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, 1, 1, 1)
+        want = oracle.conv_forward(g, x, w, b, gate=False)
+        assert rel_err(want, naive_conv(x, w, b, s)) <= 1e-5
+        for kernel in _kernels(pkg, pkg.ConvDesc.from_shape(s)):
+            got, name = _run(pkg, torch_cuda, pkg.ConvDesc.from_shape(s), w, x, b, kernel, tiling_batch=(0, 256)[k & 1])
+            if "generic" in name:
+                assert np.array_equal(got, want), (s.name, KH, KW, ph, pw)
+            assert rel_err(got, want) <= TOL, "%s via %s" % ((KH, KW, ph, pw, st), name)
+
+
+def test_seeded_slice_of_the_parity_fuzzer(pkg, oracle, synth, torch_cuda):
+    """tools/fuzz_parity.py (strides, dilations, non-square kernels and pads, conv groups, many channels, skewed
+    sparsity, fused ReLU, foreign tiling batches; every kernel family against the oracle, the generic kernel bit for
+    bit): 240 cases of one seed here, tens of thousands per round on the GPU box (profiles/r05_fuzz.md)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import fuzz_parity
+    with open(os.devnull, "w") as sink:
+        ran, lines, by_name = fuzz_parity.fuzz(240, 5, out=sink)
+    assert not lines, "\n".join(lines[:10])
+    assert ran >= 800 and sum(v for n, v in by_name.items() if "jit" in n) >= 150
+
+
 def test_randomised_pointwise_layers_with_many_output_channels(pkg, oracle, synth, torch_cuda):
     """Seeded random pointwise layers with 130 .. 400 output channels on small images, tiled as for a
     batch of 256 (one image or a few per workgroup, packed single-row planes, no tile B, one quad per

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""GPU box: seeded random convolution geometries through every kernel family against the oracle -- wider than the
+suite's randomised tests (strides, dilations, non-square kernels and pads, conv groups, up to 600 channels, skewed
+sparsity, fused ReLU, tilings of batches the inputs do not have).  The oracle (oracle/, the CPU restatement of the
+reference's loop nest) is the checker, as in tests/.
+    python tools/fuzz_parity.py [cases] [seed] > gpurun_out/fuzz.txt
+Prints one line per failure (everything needed to rebuild the case) and a summary; exit code 1 on any failure."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+TOL = 5e-5
+
+
+def rel_err(got, want):
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64)).max() if got.size else 0.0
+    return d / max(1.0, float(np.abs(want).max()) if want.size else 1.0)
+
+
+def fuzz(cases, seed, out=sys.stdout):
+    """Runs `cases` random geometries; returns (kernel runs, failure lines, runs per kernel name)."""
+    pkg, oracle = ge.load_package(), ge.load_oracle()
+    synth = pkg.synth
+    rng = np.random.RandomState(seed)
+    dev = torch.device("cuda:0")
+    kernels = {"generic": pkg.KERNEL_GENERIC, "auto": pkg.KERNEL_AUTO, "tiled": pkg.KERNEL_TILED, "jit": pkg.KERNEL_JIT,
+               "dense": pkg.KERNEL_DENSE}
+    ran, failed, by_name, lines = 0, 0, {}, []
+
+    def report(line):
+        lines.append(line)
+        print(line, file=out, flush=True)
+    t0 = time.time()
+    for k in range(cases):
+        cls = k % 4          # 0: anything goes, 1: stride 1 (the LDS-tiled families), 2: pointwise, 3: many channels
+        KH = int(rng.choice([1, 1, 2, 3, 3, 3, 4, 5, 7]))
+        KW = KH if rng.randint(4) else int(rng.choice([1, 2, 3, 5]))
+        if cls == 2:
+            KH = KW = 1
+        sh, sw = (1, 1) if cls in (1, 2, 3) and rng.randint(4) else (int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 3])))
+        if cls == 2 and rng.randint(3) == 0:
+            sh = sw = 2
+        dh, dw = (1, 1) if cls != 0 or rng.randint(3) else (int(rng.choice([1, 2])), int(rng.choice([1, 2, 3])))
+        ph = int(rng.randint(0, KH)) if KH > 1 else 0
+        pw = int(rng.randint(0, KW)) if KW > 1 else 0
+        if rng.randint(8) == 0:
+            ph, pw = ph + 1, pw + 2         # more padding than the kernel reaches
+        eh, ew = dh * (KH - 1) + 1, dw * (KW - 1) + 1
+        H = int(rng.randint(max(eh - 2 * ph, 1), 34))
+        W = int(rng.randint(max(ew - 2 * pw, 1), 66 if cls != 3 else 30))
+        group = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        if cls == 3:
+            C, M = group * int(rng.randint(40, 200)), group * int(rng.randint(30, 200))
+            N = int(rng.randint(1, 5))
+        else:
+            C, M = group * int(rng.randint(1, 40)), group * int(rng.randint(1, 70))
+            N = int(rng.randint(1, 20))
+        sp = float(rng.choice([0.0, 0.3, 0.5, 0.7, 0.8, 0.9, 0.95, 0.99, 1.0]))
+        dist = str(rng.choice(["uniform", "uniform", "channel", "zero_inputs", "filters_tail"]))
+        bias, relu = bool(rng.randint(2)), bool(rng.randint(3) == 0)
+        s = synth.shape("fz%d" % k, N, C, H, W, M, KH, KW=KW, pad=ph, pad_w=pw, stride=sh, stride_w=sw, dil=dh, dil_w=dw,
+                        group=group, sparsity=sp, bias=bias)
+        try:
+            w = synth.pruned_weights(s, 1000 + k, dist=dist)
+        except Exception:
+            w = synth.pruned_weights(s, 1000 + k)
+        b, x = synth.bias_vector(s, 2000 + k), synth.activations(s, 3000 + k)
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, s.dil_h, s.dil_w, s.group)
+        want = oracle.conv_forward(g, x, w, b, gate=False)
+        if relu:
+            want = np.maximum(want, 0.0)
+        tb = int(rng.choice([0, 0, 64, 256, 257, 1000]))
+        desc = pkg.ConvDesc.from_shape(s, fuse_relu=relu)
+        xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        bd = torch.from_numpy(b).to(dev) if b is not None else None
+        for kn, kernel in kernels.items():
+            opts = {"tiling_batch": tb}
+            if kn == "auto" and rng.randint(2):
+                opts["dense_threshold_pct"] = 100         # keep AUTO on the sparse kernels
+            try:
+                plan = pkg.Plan(desc, kernel=kernel, **opts)
+            except Exception as e:      # a forced kernel that does not cover the geometry says so at plan creation
+                if kn in ("tiled", "jit"):
+                    continue
+                report("FAIL create %s %s: %s" % (kn, tuple(s), e))
+                failed += 1
+                continue
+            try:
+                plan.weight_align(w)
+                got = plan.forward(xd, bd).cpu().numpy()
+                name = plan.kernel_name
+            except Exception as e:
+                if kn in ("tiled", "jit") and "requested" in str(e):      # a forced kernel that does not cover the geometry says so
+                    plan.close()
+                    continue
+                report("FAIL run %s %s tb=%d dist=%s relu=%d: %s" % (kn, tuple(s), tb, dist, relu, e))
+                failed += 1
+                plan.close()
+                continue
+            plan.close()
+            ran += 1
+            by_name[name] = by_name.get(name, 0) + 1
+            err = rel_err(got, want)
+            exact = "generic" in name and not np.array_equal(got, want)
+            if err > TOL or got.shape != want.shape or exact:
+                report("FAIL parity %s via %s %s tb=%d dist=%s relu=%d seed=%d k=%d: rel err %.3g%s" %
+                       (kn, name, tuple(s), tb, dist, relu, seed, k, err, " (generic kernel not bit-exact)" if exact else ""))
+                failed += 1
+        if k % 50 == 49:
+            print("# %d cases, %d runs, %d failures, %.0f s" % (k + 1, ran, failed, time.time() - t0), file=out, flush=True)
+    return ran, lines, by_name
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261004
+    ran, lines, by_name = fuzz(cases, seed)
+    print("cases %d seed %d runs %d failures %d" % (cases, seed, ran, len(lines)))
+    for n in sorted(by_name):
+        print("  %-60s %d" % (n, by_name[n]))
+    sys.exit(1 if lines else 0)
+
+
+if __name__ == "__main__":
+    main()
