@@ -39,12 +39,12 @@ def fuzz(cases, seed, out=sys.stdout):
         print(line, file=out, flush=True)
     t0 = time.time()
     for k in range(cases):
-        cls = k % 4          # 0: anything goes, 1: stride 1 (the LDS-tiled families), 2: pointwise, 3: many channels
+        cls = k % 5          # 0: anything goes, 1: stride 1 (the LDS-tiled families), 2: pointwise, 3: many channels, 4: many images
         KH = int(rng.choice([1, 1, 2, 3, 3, 3, 4, 5, 7]))
         KW = KH if rng.randint(4) else int(rng.choice([1, 2, 3, 5]))
         if cls == 2:
             KH = KW = 1
-        sh, sw = (1, 1) if cls in (1, 2, 3) and rng.randint(4) else (int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 3])))
+        sh, sw = (1, 1) if cls in (1, 2, 3, 4) and rng.randint(4) else (int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 3])))
         if cls == 2 and rng.randint(3) == 0:
             sh = sw = 2
         dh, dw = (1, 1) if cls != 0 or rng.randint(3) else (int(rng.choice([1, 2])), int(rng.choice([1, 2, 3])))
@@ -59,6 +59,10 @@ def fuzz(cases, seed, out=sys.stdout):
         if cls == 3:
             C, M = group * int(rng.randint(40, 200)), group * int(rng.randint(30, 200))
             N = int(rng.randint(1, 5))
+        elif cls == 4:       # several tiles per workgroup, tile slots past the batch, the persistent loop's rotation
+            C, M = group * int(rng.randint(1, 12)), group * int(rng.randint(1, 40))
+            N = int(rng.randint(100, 700))
+            H, W = min(H, int(rng.randint(max(eh - 2 * ph, 1), 16))), min(W, int(rng.randint(max(ew - 2 * pw, 1), 20)))
         else:
             C, M = group * int(rng.randint(1, 40)), group * int(rng.randint(1, 70))
             N = int(rng.randint(1, 20))
@@ -76,12 +80,15 @@ def fuzz(cases, seed, out=sys.stdout):
         want = oracle.conv_forward(g, x, w, b, gate=False)
         if relu:
             want = np.maximum(want, 0.0)
-        tb = int(rng.choice([0, 0, 64, 256, 257, 1000]))
+        tb = int(rng.choice([0, 0, 64, 256, 257, 1000])) if cls != 4 else 0
+        mlb = int(rng.choice([0, 0, 1])) * (4 * C * H * W * int(rng.randint(3, 60)) + 100)     # sub-batch launches
         desc = pkg.ConvDesc.from_shape(s, fuse_relu=relu)
         xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
         bd = torch.from_numpy(b).to(dev) if b is not None else None
         for kn, kernel in kernels.items():
             opts = {"tiling_batch": tb}
+            if mlb and cls == 4:
+                opts["max_launch_bytes"] = mlb
             if kn == "auto" and rng.randint(2):
                 opts["dense_threshold_pct"] = 100         # keep AUTO on the sparse kernels
             try:
