@@ -32,7 +32,7 @@ def fuzz(cases, seed, out=sys.stdout):
     dev = torch.device("cuda:0")
     kernels = {"generic": pkg.KERNEL_GENERIC, "auto": pkg.KERNEL_AUTO, "tiled": pkg.KERNEL_TILED, "jit": pkg.KERNEL_JIT,
                "dense": pkg.KERNEL_DENSE}
-    ran, failed, by_name, lines = 0, 0, {}, []
+    ran, failed, by_name, lines, imports = 0, 0, {}, [], 0
 
     def report(line):
         lines.append(line)
@@ -111,6 +111,28 @@ def fuzz(cases, seed, out=sys.stdout):
                 failed += 1
                 plan.close()
                 continue
+            # one plan in four hands its aligned form (CSR + channel deal + code object) to a fresh plan, as a rank does to
+            # the others (shard.py), and one in four of those receivers has another tiling batch: the receiver's result
+            # must be the sender's, bit for bit, when it runs the same kernel
+            if kn in ("auto", "jit") and rng.randint(4) == 0:
+                try:
+                    blob = plan.export_aligned()
+                    ropts = dict(opts)
+                    if rng.randint(4) == 0:
+                        ropts["tiling_batch"] = 64 if tb != 64 else 256
+                    recv = pkg.Plan(desc, kernel=kernel, **ropts)
+                    recv.import_aligned(blob)
+                    got2 = recv.forward(xd, bd).cpu().numpy()
+                    name2 = recv.kernel_name
+                    recv.close()
+                    imports += 1
+                    if rel_err(got2, want) > TOL or (name2 == name and ropts == opts and not np.array_equal(got2, got)):
+                        report("FAIL import %s via %s -> %s %s tb=%d dist=%s seed=%d k=%d: rel err %.3g, same bits %s" %
+                               (kn, name, name2, tuple(s), tb, dist, seed, k, rel_err(got2, want), np.array_equal(got2, got)))
+                        failed += 1
+                except Exception as e:
+                    report("FAIL import %s %s tb=%d seed=%d k=%d: %s" % (kn, tuple(s), tb, seed, k, e))
+                    failed += 1
             plan.close()
             ran += 1
             by_name[name] = by_name.get(name, 0) + 1
@@ -122,6 +144,7 @@ def fuzz(cases, seed, out=sys.stdout):
                 failed += 1
         if k % 50 == 49:
             print("# %d cases, %d runs, %d failures, %.0f s" % (k + 1, ran, failed, time.time() - t0), file=out, flush=True)
+    by_name["(aligned forms handed to a fresh plan)"] = imports
     return ran, lines, by_name
 
 
