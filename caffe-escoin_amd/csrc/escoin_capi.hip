@@ -171,23 +171,26 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
       // 507 output tiles fill the 512 MFMA slots exactly) and > 90 % (res2, 64 output channels: half-empty
       // 64 x 128 tiles) -- no single density separates them, what WeightAlign knows about the two kernels does:
       //   dense  = rounds of 128 x 128 (64 x 128 when a group has <= 64 channels) output tiles on 512 slots at
-      //            110 TFLOP/s (x 0.7 for the narrow tiles), no faster than the blobs at 4.0 TB/s;
-      //   sparse = 25 us + 2 * pixels * nonzeros at 68 TFLOP/s (3x3 / 5x5) or 58 (1x1), no faster than the
-      //            blobs at 4.8 TB/s.
-      // Worst regret over the 14 shapes x 12 sparsities of the table: 6.6 % (a fixed 50 % cut: 42 %).  The model
-      // only ever decides ABOVE the cut; below it the sparse kernel always won, and above 90 % density the dense one
-      // (an unpruned layer is never turned into megabytes of code).  An explicit dense_threshold_pct option is
-      // obeyed as given.
+      //            120 TFLOP/s (x 0.7 for the narrow tiles), no faster than the blobs at 4.0 TB/s;
+      //   sparse = 50 us + 2 * pixels * nonzeros at 80 TFLOP/s (3x3 / 5x5), 20 us + ... at 68 (1x1), no faster than
+      //            the blobs at 4.8 TB/s.
+      // Re-fitted in round 5 (profiles/r05_crossover.md; round 4's constants -- 25 us + 68 / 58 TFLOP/s against 110 --
+      // were fitted to generated code that still moved a literal per nonzero, and on round 5's code sent res2 @10 %
+      // sparsity to the dense kernel at 782 us against 588, res4 / res5 @20 % at 688 / 682 against 583 / 574).
+      // Worst regret over the 14 shapes x 12 sparsities of the table: 7.7 % (round 4's constants on this table: 33 %;
+      // a fixed 50 % cut: 42 %).  The model only ever decides ABOVE the cut; below it the sparse kernel always won, and
+      // above 92 % density the dense one (an unpruned layer is never turned into megabytes of code).  An explicit
+      // dense_threshold_pct option is obeyed as given.
       auto model_says_dense = [&](long nnz_g) {
-        if ((double)nnz_g > 0.9 * per_group) return true;
+        if ((double)nnz_g > 0.92 * per_group) return true;
         const double n = (double)(p->tiling_batch > 0 ? p->tiling_batch : g.d.N);
         const double pix = n * g.OH * g.OW;
         const int tm = g.Mg <= 64 ? 64 : 128;
         const double tiles = std::ceil((double)g.Mg / tm) * std::ceil(pix / 128.0);
         const double rounds = std::ceil(tiles / 512.0);
         const double byt = 4.0 * n * ((double)g.Cg * g.d.H * g.d.W + (double)g.Mg * g.OH * g.OW);
-        const double t_dense = std::max(rounds * 2.0 * tm * 128.0 * g.kdim / (110e6 * (tm == 64 ? 0.7 : 1.0) / 512.0), byt / 4.0e6);
-        const double t_sparse = std::max(25.0 + 2.0 * pix * (double)nnz_g / (g.d.KH * g.d.KW > 1 ? 68e6 : 58e6), byt / 4.8e6 + 8.0);
+        const double t_dense = std::max(rounds * 2.0 * tm * 128.0 * g.kdim / (120e6 * (tm == 64 ? 0.7 : 1.0) / 512.0), byt / 4.0e6);
+        const double t_sparse = std::max((g.d.KH * g.d.KW > 1 ? 50.0 : 20.0) + 2.0 * pix * (double)nnz_g / (g.d.KH * g.d.KW > 1 ? 80e6 : 68e6), byt / 4.8e6 + 8.0);
         return t_dense < t_sparse;
       };
       const bool use_model = p->dense_threshold_pct < 0 && fast_sparse && jit_available() &&

@@ -898,10 +898,10 @@ def test_dense_stream_k_fixup(pkg, oracle, synth, torch_cuda):
 
 
 def test_kernel_auto_follows_the_measured_crossover(pkg, synth, torch_cuda):
-    """What KERNEL_AUTO resolves to, per BASELINE shape (profiles/r04_crossover.md): generated code at every point of
+    """What KERNEL_AUTO resolves to, per BASELINE shape (profiles/r04_crossover.md, r05_crossover.md): generated code at every point of
     the 50-95 % sparsity sweep of the ResNet-50, AlexNet and GoogLeNet sets (it is ahead of the stream kernel and of
     the dense kernel at each of them); the dense MFMA kernel for unpruned layers; above 50 % density whatever the
-    two-kernel cost model says (res2 stays sparse down to 10 % sparsity, AlexNet conv3 goes dense at 40 %); layers the
+    two-kernel cost model says (res2 stays sparse down to 10 % sparsity, AlexNet conv3 goes dense at 30 %); layers the
     tiled kernels do not cover (stride 2) go dense above 4 % density, to the generic kernel below."""
     gl = synth.googlenet_1x1(N=256)
     layers = synth.resnet50_3x3(N=256) + synth.alexnet(N=128) + [gl[0], gl[1], gl[5], gl[9], gl[25], gl[33], gl[37]]
@@ -926,10 +926,14 @@ def test_kernel_auto_follows_the_measured_crossover(pkg, synth, torch_cuda):
         plan.close()
         return c
     rn, al = synth.resnet50_3x3(N=256), synth.alexnet(N=128)
-    assert choice(rn[0], 0.2) == pkg.KERNEL_JIT          # res2: 607 us against 783 dense
-    assert choice(rn[2], 0.3) == pkg.KERNEL_JIT          # res4: 605 against 692
-    assert choice(al[1], 0.4) == pkg.KERNEL_DENSE        # AlexNet conv3: 409 against 380
-    assert choice(gl[5], 0.3) == pkg.KERNEL_DENSE        # inception_3b 256@28x28 -> 128: 174 against 143
+    # (profiles/r05_crossover.md: the model's constants were re-fitted to round 5's generated code)
+    assert choice(rn[0], 0.1) == pkg.KERNEL_JIT          # res2: 588 us against 782 dense
+    assert choice(rn[2], 0.2) == pkg.KERNEL_JIT          # res4: 583 against 688
+    assert choice(rn[3], 0.1) == pkg.KERNEL_DENSE        # res5: 682 against 636 (the model's worst cell: 7 % behind)
+    assert choice(al[1], 0.3) == pkg.KERNEL_DENSE        # AlexNet conv3: 369 against 413
+    assert choice(al[2], 0.1) == pkg.KERNEL_JIT          # AlexNet conv4: 405 against 434
+    assert choice(gl[5], 0.3) == pkg.KERNEL_DENSE        # inception_3b 256@28x28 -> 128: 139 against 149
+    assert choice(gl[5], 0.4) == pkg.KERNEL_JIT          # ... 137 against 139
     # stride 2, 1x1 (ResNet-50's res3a_branch2a, pruned): the pointwise path over a strided view of the bottom blob
     s2 = synth.shape("res3a_branch2a", 2, 256, 56, 56, 128, 1, stride=2, bias=False, sparsity=0.9)
     plan = pkg.Plan(pkg.ConvDesc.from_shape(s2), tiling_batch=256)
