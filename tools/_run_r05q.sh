@@ -1,6 +1,7 @@
 #!/bin/bash
-# r05q: the whole GPU suite + smoke on the final binary
-set -o pipefail
+# r05q: workgroup lifetimes of the layers with several tiles per workgroup (what an atomic tile queue could balance)
 O=gpurun_out/r05q; mkdir -p $O
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke.log
+for L in res2 res3 res4 goog0 goog5; do
+  ESCOIN_LIB=$PWD/tools/ab/libescoin_abl.so ESCOIN_PROF=1 ONE_LAYER_BUFS=4 timeout -k 10 120 python tools/one_layer.py $L 2 > $O/stamp_$L.log 2>&1
+  echo "== $L"; grep -i "life\|xcd\|percentile\|start" $O/stamp_$L.log | head -12
+done
