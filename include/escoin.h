@@ -220,7 +220,11 @@ ESCOIN_API int escoin_forward(escoin_plan *plan, const float *bottom_dev, const 
 
 /* caffe_gpu_sconv<float>, math_functions.cu:590-704 (bias applied iff FUSE_RELU, as
  * there: :215,421 vs :282).  `input` is the padded image(s), per-image stride
- * ifmap_size*num_groups floats (math_functions.cu:566). */
+ * ifmap_size*num_groups floats (math_functions.cu:566).  Like the reference's kernel it reads
+ * the last row's right padding out of the floats that FOLLOW the row; the reference's buffer
+ * (base_conv_layer.cpp:71) has those behind the last channel only when pad_h >= 1 -- with
+ * pad_h == 0 < pad_w the caller must provide pad_w zero floats more behind the last image
+ * (the layer-level path, escoin_forward, needs no padded buffer and has no such case). */
 ESCOIN_API int escoin_gpu_sconv(int fuse_relu, int num, const float *input, int ifmap_size,
                      const int *rowptr, const int *colidx, const float *values,
                      const float *bias, int height, int width, int pad_h, int pad_w,
