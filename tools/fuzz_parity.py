@@ -24,6 +24,56 @@ def rel_err(got, want):
     return d / max(1.0, float(np.abs(want).max()) if want.size else 1.0)
 
 
+def dropin_chain(pkg, oracle, synth, dev, s, w, x, k):
+    """The math_functions-level drop-ins on the reference's own layouts, as base_conv_layer.cpp calls them: device
+    dense -> CSR, stretch, padded copy, caffe_gpu_sconv's replacement.  Returns None or what differed."""
+    import ctypes as C
+    L = pkg.lib()
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, s.dil_h, s.dil_w)
+    kdim = s.C * s.KH * s.KW
+    P = lambda t: C.c_void_p(t.data_ptr())
+    A = torch.from_numpy(np.ascontiguousarray(w.reshape(s.M, kdim))).to(dev)
+    vals = torch.zeros(s.M * kdim, device=dev)
+    cols = torch.zeros(s.M * kdim, dtype=torch.int32, device=dev)
+    rowp = torch.zeros(s.M + 1, dtype=torch.int32, device=dev)
+    perrow = torch.zeros(s.M, dtype=torch.int32, device=dev)
+    nnz = C.c_int()
+    if L.escoin_gpu_sparse_dense2csr(s.M, kdim, P(A), P(perrow), P(vals), P(rowp), P(cols), C.byref(nnz), None) != 0:
+        return "dense2csr failed"
+    orp, oci, ova = oracle.dense2csr(w.reshape(s.M, kdim))
+    if nnz.value != len(oci) or not np.array_equal(rowp.cpu().numpy(), orp) or \
+            not np.array_equal(cols.cpu().numpy()[:nnz.value], oci) or not np.array_equal(vals.cpu().numpy()[:nnz.value], ova):
+        return "dense2csr differs from the oracle's"
+    if L.escoin_gpu_stretch(P(rowp), P(cols), s.M, s.H, s.W, s.pad_h, s.pad_w, s.KH, s.KW, None) != 0:
+        return "stretch failed"
+    if not np.array_equal(cols.cpu().numpy()[:nnz.value], oracle.stretch(orp, oci, s.KH, s.KW, s.H, s.W, s.pad_h, s.pad_w)):
+        return "stretch differs from the oracle's"
+    N = x.shape[0]
+    ifmap = s.C * (s.H + s.pad_h) * (s.W + s.pad_w)
+    padded = torch.zeros(N * ifmap + oracle.padded_len(g), device=dev)
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    for n in range(N):
+        if L.escoin_copy_input_data(C.c_void_p(padded.data_ptr() + 4 * n * ifmap), C.c_void_p(xd.data_ptr() + 4 * n * s.C * s.H * s.W),
+                                    s.C, s.H, s.W, s.pad_h, s.pad_w, None) != 0:
+            return "copy_input_data failed"
+    oh, ow = oracle.out_hw(g)
+    out = torch.zeros(N, s.M, oh, ow, device=dev)
+    bias = synth.uniform(7000 + k, s.M, -0.1, 0.1)
+    bd = torch.from_numpy(bias).to(dev)
+    base = oracle.conv_forward(g, x, w, None, gate=False)
+    for relu in (0, 1):
+        if L.escoin_gpu_sconv(relu, N, P(padded), ifmap, P(rowp), P(cols), P(vals), P(bd), s.H, s.W, s.pad_h, s.pad_w, s.stride_h,
+                              s.stride_w, s.dil_h, s.dil_w, s.KH, s.KW, P(out), s.M, 1, None) != 0:
+            return "gpu_sconv failed"
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        if relu == 0 and not np.array_equal(got, base):
+            return "gpu_sconv not bit-exact (rel err %.3g)" % rel_err(got, base)
+        if relu == 1 and rel_err(got, np.maximum(base + bias[None, :, None, None], 0)) > 1e-6:
+            return "gpu_sconv with bias + ReLU off by %.3g" % rel_err(got, np.maximum(base + bias[None, :, None, None], 0))
+    return None
+
+
 def fuzz(cases, seed, out=sys.stdout):
     """Runs `cases` random geometries; returns (kernel runs, failure lines, runs per kernel name)."""
     pkg, oracle = ge.load_package(), ge.load_oracle()
@@ -32,7 +82,7 @@ def fuzz(cases, seed, out=sys.stdout):
     dev = torch.device("cuda:0")
     kernels = {"generic": pkg.KERNEL_GENERIC, "auto": pkg.KERNEL_AUTO, "tiled": pkg.KERNEL_TILED, "jit": pkg.KERNEL_JIT,
                "dense": pkg.KERNEL_DENSE}
-    ran, failed, by_name, lines, imports = 0, 0, {}, [], 0
+    ran, failed, by_name, lines, imports, chains = 0, 0, {}, [], 0, 0
 
     def report(line):
         lines.append(line)
@@ -80,6 +130,12 @@ def fuzz(cases, seed, out=sys.stdout):
         want = oracle.conv_forward(g, x, w, b, gate=False)
         if relu:
             want = np.maximum(want, 0.0)
+        if group == 1 and k % 3 == 0 and N * C * H * W < 400000:
+            why = dropin_chain(pkg, oracle, synth, dev, s, w, x, k)
+            chains += 1
+            if why:
+                report("FAIL drop-in chain %s seed=%d k=%d: %s" % (tuple(s), seed, k, why))
+                failed += 1
         tb = int(rng.choice([0, 0, 64, 256, 257, 1000])) if cls != 4 else 0
         mlb = int(rng.choice([0, 0, 1])) * (4 * C * H * W * int(rng.randint(3, 60)) + 100)     # sub-batch launches
         desc = pkg.ConvDesc.from_shape(s, fuse_relu=relu)
@@ -145,6 +201,7 @@ def fuzz(cases, seed, out=sys.stdout):
         if k % 50 == 49:
             print("# %d cases, %d runs, %d failures, %.0f s" % (k + 1, ran, failed, time.time() - t0), file=out, flush=True)
     by_name["(aligned forms handed to a fresh plan)"] = imports
+    by_name["(math_functions-level drop-in chains)"] = chains
     return ran, lines, by_name
 
 
