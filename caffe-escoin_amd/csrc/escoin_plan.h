@@ -60,6 +60,7 @@ struct TiledConfig {
   int dma_period = 0;        // quads covered by the quad table (lcm of the plane size and 64)
   int jit_pref = 0;          // code touches at the start of every unit
   bool jit_chain = false;    // a tile's units run as one chain (jit_codegen.h ChainPlan)
+  bool jit_self_zero = false;  // block 0's unit initialises the accumulators (jit_codegen.h Options::self_zero)
   float deal_slowest_over_mean = 1.f, deal_worst_block = 1.f;   // balance of the channel deal (jit_codegen.h Program)
   std::string info;          // escoin_plan_tiling_info
 };

@@ -84,8 +84,10 @@ struct Lds {
 // n_pref > 0: the unit starts with n_pref loads over the next unit's code; returns the index (in
 // `c`) of the distance literal to patch (0: none).
 // blk / n_icb: which block of its oc-group's chain this unit is (chaining only).
+// n_idx: accumulator quads per tile the epilogue reads (channels per wave x kernel columns): with Options::self_zero
+// block 0's unit leaves every one of them initialised.
 size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const std::vector<Piece> &pieces,
-                 const Options &opt_in, int n_pref, int wave, int blk, int n_icb) {
+                 const Options &opt_in, int n_pref, int wave, int blk, int n_icb, int n_idx) {
   Options opt = opt_in;
   if (opt.prio_waves > 0 && (wave < 0 || wave >= opt.prio_waves)) opt.prio_rows = 0;
   size_t patch = 0;
@@ -108,6 +110,24 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
     enc_v_add_u32_s(c, kVTabAddr, kSTabDelta, kVTabAddr);
   }
   const int n = (opt.ablate & 8) ? 0 : (int)rows.size();
+  // (self_zero) which accumulator quads this unit still has to initialise: all of them in block 0's unit
+  const bool init_acc = opt.self_zero && blk == 0 && !(opt.ablate & 1);
+  std::vector<char> fresh(init_acc ? (size_t)n_idx : 0, 1);
+  if (init_acc) {
+    std::vector<char> touched((size_t)n_idx, 0);
+    for (int k = 0; k < n; ++k)
+      for (const Rec &r : rows[k].recs) touched[(size_t)r.idx] = 1;
+    for (int i = 0; i < n_idx; ++i)
+      if (!touched[(size_t)i]) {
+        enc_pk_zero(c, kAccA + 4 * i);
+        enc_pk_zero(c, kAccA + 4 * i + 2);
+        if (!opt.one_tile) {
+          enc_pk_zero(c, kAccB + 4 * i);
+          enc_pk_zero(c, kAccB + 4 * i + 2);
+        }
+        fresh[(size_t)i] = 0;
+      }
+  }
   // Weights through the scalar cache (Options::sweights): which line and slot every nonzero of the unit's walk takes.
   // A line ends where the next ROW would not fit (so that the switch to a line sits at a row top, where the wave waits
   // for LDS anyway); a row of more than 16 nonzeros runs over several lines.
@@ -262,21 +282,28 @@ size_t emit_unit(std::vector<uint32_t> &c, const std::vector<Row> &rows, const s
       if (opt.ablate & 1) continue;
       const int a = 4 * flat[j]->idx;
       // (timing only: 512 = an s_nop behind every FMA -- four more instructions and 16 more bytes per nonzero)
+      const bool first = init_acc && fresh[(size_t)flat[j]->idx];     // the quad's first product: multiply, do not accumulate
       auto fma = [&](int acc, int x) {
         if (sw) {
           const int pair = ((line_of[j] & 1) ? kSWBuf1 : kSWBuf0) + (slot_of[j] & ~1);
-          if (slot_of[j] & 1) enc_pk_fma_hi(c, acc, pair, x);
+          if (first) {
+            if (slot_of[j] & 1) enc_pk_mul_hi(c, acc, pair, x);
+            else enc_pk_mul(c, acc, pair, x);
+          } else if (slot_of[j] & 1) enc_pk_fma_hi(c, acc, pair, x);
           else enc_pk_fma(c, acc, pair, x);
           return;
         }
-        enc_pk_fma(c, acc, sreg(j), x);
+        if (first) enc_pk_mul(c, acc, sreg(j), x);
+        else enc_pk_fma(c, acc, sreg(j), x);
         if (opt.ablate & 512) enc_nop(c);
       };
       fma(kAccA + a, xa);
       fma(kAccA + a + 2, xa + 2);
-      if (opt.one_tile) continue;
-      fma(kAccB + a, xb);
-      fma(kAccB + a + 2, xb + 2);
+      if (!opt.one_tile) {
+        fma(kAccB + a, xb);
+        fma(kAccB + a + 2, xb + 2);
+      }
+      if (first) fresh[(size_t)flat[j]->idx] = 0;
     }
   }
   // whatever the rows did not take (short or empty units): two at a time
@@ -408,7 +435,7 @@ void emit_chain(const ConvGeom &g, const Tiling &t, const std::vector<int> &rowp
     while ((p.code.size() * 4) % kUnitAlign) enc_nop(p.code);
     p.off[blk] = (uint32_t)(p.code.size() * 4);
     const size_t at = p.code.size();
-    patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref, t.pix_waves == 1 ? ocg % t.oc_waves : -1, blk, t.n_icb));
+    patches.push_back(emit_unit(p.code, live, pieces, opt, n_pref, t.pix_waves == 1 ? ocg % t.oc_waves : -1, blk, t.n_icb, t.G * g.KW));
     p.max_unit = std::max(p.max_unit, (p.code.size() - at) * 4);
   }
   // the distances: unit blk touches the code of unit (blk + 1) % n_icb

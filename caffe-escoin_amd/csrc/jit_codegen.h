@@ -162,6 +162,22 @@ constexpr int kSWBuf0 = 56, kSWBuf1 = 72;   // two buffers of 16 weights: s[56:7
 constexpr int kSWBase = 88;                 // s[88:89]: address of the unit's weight lines
 constexpr int kSWLine = 16;                 // weights per line (one s_load_dwordx16, 64 bytes)
 inline void enc_nop(std::vector<uint32_t> &c) { c.push_back(0xBF800000u); }
+// ---- accumulators initialised by the code itself (Options::self_zero below) ----
+// v_pk_mul_f32 v[acc:acc+1], s[sw:sw+1], v[x:x+1] op_sel_hi:[0,1] -- the first product of an accumulator pair
+inline void enc_pk_mul(std::vector<uint32_t> &c, int acc, int sw, int x) {
+  c.push_back(0xD3B14000u | (uint32_t)acc);
+  c.push_back((uint32_t)sw | ((256u + (uint32_t)x) << 9) | (2u << 27));
+}
+// v_pk_mul_f32 v[acc:acc+1], s[sw:sw+1], v[x:x+1] op_sel:[1,0] (the HIGH dword of the SGPR pair)
+inline void enc_pk_mul_hi(std::vector<uint32_t> &c, int acc, int sw, int x) {
+  c.push_back(0xD3B14800u | (uint32_t)acc);
+  c.push_back((uint32_t)sw | ((256u + (uint32_t)x) << 9) | (3u << 27));
+}
+// v_pk_mov_b32 v[acc:acc+1], 0, 0
+inline void enc_pk_zero(std::vector<uint32_t> &c, int acc) {
+  c.push_back(0xD3B34000u | (uint32_t)acc);
+  c.push_back(0x18010080u);
+}
 
 // What the generated code must know to stage the next block's planes itself.
 struct DmaPlan {
@@ -235,6 +251,11 @@ struct Options {
                           // load in flight, which can only make them wait longer.  4.06 instead of 5 instructions and 36 instead
                           // of 40 code bytes per nonzero; for the 3x3 / 5x5 layers (their kernel instantiation pays 34 more
                           // clobbered SGPRs around the call: sconv_tiled.hip)
+  int self_zero = 0;      // 1: the kernel body does not clear the accumulators at a tile's top (192 vector moves per wave and
+                          // tile: 7 us of a 120 us res2 launch) -- block 0's unit does: the FIRST product of an accumulator pair is
+                          // a v_pk_mul_f32 instead of an FMA onto zero (the same value; a product of -0 keeps its sign where
+                          // 0 + -0 gave +0), and the pairs block 0 never touches are cleared at its top (rare: a (channel, kernel
+                          // column) without a nonzero in the block's channels)
   int one_tile = 0;       // set by build_program: the tiling leaves tile B without rows, its reads and FMAs
                           // are not generated (-1: never, ESCOIN_JIT_ONE_TILE=0)
 };

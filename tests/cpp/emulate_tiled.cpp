@@ -59,6 +59,7 @@ struct JitChainCtx {
 };
 
 static long g_weight_lines = 0;      // s_load_dwordx16 executed (Options::sweights)
+static long g_first_products = 0, g_cleared = 0;   // v_pk_mul_f32 / v_pk_mov_b32 executed (Options::self_zero)
 static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w, const std::vector<float> &lds,
                         const std::vector<uint32_t> &laneA /* LDS byte address of the lane's tile-A quad */,
                         JitDmaCtx *dma = nullptr, JitPref *pref = nullptr, JitChainCtx *chain = nullptr) {
@@ -330,9 +331,42 @@ static int jit_run_unit(const std::vector<uint32_t> &code, size_t pc, JitWave &w
       std::memcpy(&wv, &sreg[sw + hi], 4);
       for (int lane = 0; lane < 64; ++lane) {
         float *V = &w.v[(size_t)lane * 256];
+        if (V[acc] != V[acc] || V[acc + 1] != V[acc + 1]) { printf("jit: FMA onto an accumulator nothing initialised (v%d)\n", acc); return 3; }
         V[acc] = std::fmaf(wv, V[x], V[acc]);
         V[acc + 1] = std::fmaf(wv, V[x + 1], V[acc + 1]);
       }
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFFFFF700u) == 0xD3B14000u) {   // v_pk_mul_f32 acc, s[w:w+1], v[x:x+1] op_sel_hi:[0,1] | op_sel:[1,0]: a quad's FIRST product (Options::self_zero)
+      const int acc = (int)(d0 & 0xFF), sw = (int)(d1 & 0x1FF);
+      const int hi = (d0 >> 11) & 1;
+      const int x = (int)((d1 >> 9) & 0x1FF) - 256;
+      if (((d1 >> 18) & 0x1FF) != 0 || acc < 64 || acc > 254 || (acc & 1) || x < 36 || (x > 58 && (x < 160 || x > 254 || acc >= 160)) || sw > 101 || (sw & 1) ||
+          (d1 >> 27) != (hi ? 3u : 2u) || (hi && sw < 56)) { printf("jit: bad v_pk_mul_f32 operands\n"); return 3; }
+      if (is_pending(x) || is_pending(x + 1)) { printf("jit: product reads v%d before its LDS read was waited for\n", x); return 3; }
+      if (sw >= 56 && sw < 88 && smem_pending[sw >= 72 ? 1 : 0]) { printf("jit: product reads weight buffer s%d before its line was waited for\n", sw); return 3; }
+      float wv;
+      std::memcpy(&wv, &sreg[sw + hi], 4);
+      for (int lane = 0; lane < 64; ++lane) {
+        float *V = &w.v[(size_t)lane * 256];
+        if (V[acc] == V[acc] || V[acc + 1] == V[acc + 1]) { printf("jit: v_pk_mul_f32 overwrites an initialised accumulator v%d\n", acc); return 3; }
+        V[acc] = wv * V[x];
+        V[acc + 1] = wv * V[x + 1];
+      }
+      ++g_first_products;
+      pc += 8;
+      continue;
+    }
+    if ((d0 & 0xFFFFFF00u) == 0xD3B34000u && d1 == 0x18010080u) {   // v_pk_mov_b32 acc, 0, 0: a quad block 0 never touches
+      const int acc = (int)(d0 & 0xFF);
+      if (acc < 64 || acc > 254 || (acc & 1)) { printf("jit: bad v_pk_mov_b32 destination\n"); return 3; }
+      for (int lane = 0; lane < 64; ++lane) {
+        float *V = &w.v[(size_t)lane * 256];
+        if (V[acc] == V[acc] || V[acc + 1] == V[acc + 1]) { printf("jit: v_pk_mov_b32 clears an initialised accumulator v%d\n", acc); return 3; }
+        V[acc] = V[acc + 1] = 0.f;
+      }
+      ++g_cleared;
       pc += 8;
       continue;
     }
@@ -373,6 +407,7 @@ static int run(const Case &cs, bool use_jit) {
   WeightStream ws2 = build_stream(g, t, rp, ci, va);
   jit::Program jp;
   jit::DmaPlan jdma;
+  bool jit_self_zero = false;
   if (use_jit) {
     jit::Options jo;
     jo.depth = 1 + (cs.N & 1);            // both read-ahead depths and both weight placements get exercised
@@ -380,7 +415,9 @@ static int run(const Case &cs, bool use_jit) {
     jo.prio_rows = (cs.M & 1) ? 2 : 0;
     jo.hi_sets = (cs.N & 1) ? 24 : 0;     // (used only by code without a tile B: deeper read-ahead through tile B's registers)
     jo.depth_one_tile = (cs.N & 1) ? 5 + cs.N % 9 : 5;
-    jo.sweights = cs.KW != 1 && (cs.C & 3) != 1;     // weights through the scalar cache: most 3x3 / 5x5 geometries (not all: both forms stay covered)
+    jo.sweights = cs.KW != 1 && (cs.C & 3) != 1;
+    jo.self_zero = (cs.M % 3) != 0;       // the code initialises its accumulators (most geometries; the kernel's own clearing stays covered)
+    jit_self_zero = jo.self_zero != 0;     // weights through the scalar cache: most 3x3 / 5x5 geometries (not all: both forms stay covered)
     // plane DMA from inside the code wherever one wave owns an oc-group (whatever the table's size: the
     // product bounds it, the emulation does not need to)
     if (t.pix_waves == 1 && (t.waves == 8 || t.waves == 4)) {
@@ -449,7 +486,9 @@ static int run(const Case &cs, bool use_jit) {
     for (int cg = 0; cg < g.group; ++cg)
       for (int ocblk = 0; ocblk < t.n_ocblk; ++ocblk) {
         // per-wave accumulators: [wave][lane][192]
-        std::vector<float> acc((size_t)t.waves * 64 * kAccAll, 0.f);
+        // (Options::self_zero: nobody clears the accumulators for the code -- they start as NaN, and an FMA onto one is an error)
+        const float acc0 = (use_jit && jit_self_zero) ? std::nanf("") : 0.f;
+        std::vector<float> acc((size_t)t.waves * 64 * kAccAll, acc0);
         auto fill_block = [&](int blk, std::vector<float> &lds) {
           std::fill(lds.begin(), lds.end(), 0.f);
           for (int icl = 0; icl < t.icb; ++icl) {
@@ -527,6 +566,8 @@ static int run(const Case &cs, bool use_jit) {
             const int ocg = ocblk * t.oc_waves + ow_;
             if (ocg >= t.n_ocg) { printf("jit chain: a wave without an oc-group\n"); return 3; }
             JitWave jw;
+            for (int lane = 0; lane < 64; ++lane)
+              for (int r = 0; r < kAccAll; ++r) jw.v[(size_t)lane * 256 + 64 + r] = acc0;
             std::vector<uint32_t> laneA(64);
             for (int lane = 0; lane < 64; ++lane) {
               const int fr = (pw * t.tpl) * t.rows_per_slab + lane / t.S4;
@@ -750,11 +791,11 @@ static int run(const Case &cs, bool use_jit) {
   }
   const double rel = maxerr / std::fmax(1e-6, maxref);
   printf("%s%sN%d C%d %dx%d M%d K%dx%d p%d,%d g%d sp%.2f waves%d: tpl=%d S4=%d G=%d ocw=%d pw=%d tr=%d nseg=%d band=%d icb=%d/%d lds=%d "
-         "groups=%ld recs=%ld recs/group=%.2f dma=%ld lines=%ld rel_err=%.2e\n",
+         "groups=%ld recs=%ld recs/group=%.2f dma=%ld lines=%ld init=%ld+%ld rel_err=%.2e\n",
          use_jit ? "jit " : "", use_jit && jp.chained ? "chained " : "", cs.N, cs.C, cs.H, cs.W, cs.M, cs.KH, cs.KW, cs.ph, cs.pw, cs.group, cs.sparsity, cs.waves, t.tpl, t.S4, t.G,
          t.oc_waves, t.pix_waves, t.tr, t.nseg, (int)t.band_mode, t.icb, t.n_icb, t.planes_bytes,
-         ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, dma_checked, g_weight_lines, rel);
-  g_weight_lines = 0;
+         ws2.n_groups, ws2.n_records, ws2.n_groups ? (double)ws2.n_records / (double)ws2.n_groups : 0.0, dma_checked, g_weight_lines, g_first_products, g_cleared, rel);
+  g_weight_lines = g_first_products = g_cleared = 0;
   if (use_jit && jdma.on && dma_checked == 0) { printf("jit dma: nothing was checked\n"); return 3; }
   return rel <= 1e-5 ? 0 : 1;
 }

@@ -51,6 +51,27 @@ int main() {
              sd + 1, x, x + 1, acc, acc + 1);
     dump(buf, c);
   }
+  // accumulators initialised by the code (Options::self_zero)
+  for (int i = 0; i < 60; ++i) {
+    std::vector<uint32_t> c;
+    const int acc = 64 + 2 * rnd(96), x = 36 + 2 * rnd(12);
+    const int lit_pair = rnd(2) ? kSWeight0 : kSWeight1, pair = ((i & 1) ? kSWBuf1 : kSWBuf0) + 2 * rnd(8);
+    enc_pk_mul(c, acc, lit_pair, x);
+    snprintf(buf, sizeof buf, "v_pk_mul_f32 v[%d:%d], s[%d:%d], v[%d:%d] op_sel_hi:[0,1]", acc, acc + 1, lit_pair, lit_pair + 1, x, x + 1);
+    dump(buf, c);
+    c.clear();
+    enc_pk_mul(c, acc, pair, x);
+    snprintf(buf, sizeof buf, "v_pk_mul_f32 v[%d:%d], s[%d:%d], v[%d:%d] op_sel_hi:[0,1]", acc, acc + 1, pair, pair + 1, x, x + 1);
+    dump(buf, c);
+    c.clear();
+    enc_pk_mul_hi(c, acc, pair, x);
+    snprintf(buf, sizeof buf, "v_pk_mul_f32 v[%d:%d], s[%d:%d], v[%d:%d] op_sel:[1,0] op_sel_hi:[1,1]", acc, acc + 1, pair, pair + 1, x, x + 1);
+    dump(buf, c);
+    c.clear();
+    enc_pk_zero(c, acc);
+    snprintf(buf, sizeof buf, "v_pk_mov_b32 v[%d:%d], 0, 0", acc, acc + 1);
+    dump(buf, c);
+  }
   // weights through the scalar cache (Options::sweights)
   for (int i = 0; i < 60; ++i) {
     std::vector<uint32_t> c;

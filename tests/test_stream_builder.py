@@ -25,6 +25,11 @@ def test_stream_and_tiling_against_cpu_emulation(tmp_path):
     # generates, interpreted instruction by instruction
     assert text.count("rel_err=") == 40 + 40
     assert len([l for l in text.splitlines() if l.startswith("jit ")]) == 40
+    # ... most of them with code that initialises its own accumulators (first products as multiplies, the quads block 0 never
+    # touches cleared at its top; the interpreter starts those accumulators as NaN and refuses an FMA onto one)
+    init = [tuple(int(v) for v in l.split("init=")[1].split()[0].split("+")) for l in text.splitlines() if l.startswith("jit ")]
+    assert sum(1 for m, z in init if m > 0) >= 20 and sum(1 for m, z in init if z > 0) >= 3
+    assert sum(1 for m, z in init if m == 0 and z == 0) >= 8
     # ... a good part of them as chains (one call per tile), several blocks long, with one and two fills in flight
     chained = [l for l in text.splitlines() if l.startswith("jit chained ")]
     assert len(chained) >= 15

@@ -50,7 +50,7 @@ with open(os.path.join(out, "%s_stamp_profile.md" % tag), "w") as f:
         p = os.path.join(src, "stamp_%s.log" % L)
         if not os.path.exists(p):
             continue
-        life = last(p, "workgroup lifetime")
+        life = last(p, "workgroup lifetime:")
         spread = last(p, "per-WG wave spread")
         w0 = last(p, "wave0 cycles/WG")
         m = re.search(r"lifetime: (\d+) shader cycles in ([\d.]+) us -> ([\d.]+) GHz", life)
