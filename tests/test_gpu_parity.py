@@ -802,6 +802,51 @@ def test_padding_in_one_direction_only(pkg, oracle, synth, torch_cuda):
             assert rel_err(got, want) <= TOL, "%s via %s" % ((KH, KW, ph, pw, st), name)
 
 
+def test_forward_is_capturable_into_a_hip_graph(pkg, oracle, synth, torch_cuda):
+    """escoin_forward launches on the stream it is given and neither synchronises nor allocates: a host framework may
+    capture its forward pass (every kernel family here) into a HIP graph and replay it on new bottom data
+    (tools/graph_step.py times a whole step that way: within 1 % of launching layer by layer)."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    cases = [(synth.shape("g3", 5, 24, 14, 14, 40, 3, pad=1, sparsity=0.9), pkg.KERNEL_JIT, {"tiling_batch": 256}),
+             (synth.shape("g1", 6, 64, 7, 7, 72, 1, sparsity=0.95), pkg.KERNEL_AUTO, {"tiling_batch": 256}),
+             (synth.shape("gs", 4, 16, 12, 12, 24, 3, pad=1, sparsity=0.8), pkg.KERNEL_TILED, {}),
+             (synth.shape("gd", 3, 32, 14, 14, 64, 1, sparsity=0.0), pkg.KERNEL_DENSE, {}),
+             (synth.shape("gg", 3, 8, 9, 9, 12, 3, pad=1, stride=2, sparsity=0.9), pkg.KERNEL_GENERIC, {})]
+    layers = []
+    for k, (s, kernel, opts) in enumerate(cases):
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=kernel, **opts)
+        w, b = synth.pruned_weights(s, 8100 + k), synth.bias_vector(s, 8200 + k)
+        plan.weight_align(w)
+        x = torch.zeros((s.N, s.C, s.H, s.W), device=dev)
+        y = torch.zeros((s.N, s.M) + tuple(plan.out_hw), device=dev)
+        layers.append((s, plan, w, b, x, torch.from_numpy(b).to(dev) if b is not None else None, y))
+
+    def step():
+        for s, plan, w, b, x, bd, y in layers:
+            plan.forward(x, bd, y)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                      # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for rnd in range(2):            # two replays on different bottom data
+        for k, (s, plan, w, b, x, bd, y) in enumerate(layers):
+            x.copy_(torch.from_numpy(synth.activations(s, 8300 + 10 * rnd + k)).to(dev))
+            y.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        for k, (s, plan, w, b, x, bd, y) in enumerate(layers):
+            geo = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, 1, 1, 1)
+            want = oracle.conv_forward(geo, synth.activations(s, 8300 + 10 * rnd + k), w, b, gate=False)
+            assert rel_err(y.cpu().numpy(), want) <= TOL, (s.name, plan.kernel_name, rnd)
+    for s, plan, *_ in layers:
+        plan.close()
+
+
 def test_seeded_slice_of_the_parity_fuzzer(pkg, oracle, synth, torch_cuda):
     """tools/fuzz_parity.py (strides, dilations, non-square kernels and pads, conv groups, many channels, skewed
     sparsity, fused ReLU, foreign tiling batches; every kernel family against the oracle, the generic kernel bit for
