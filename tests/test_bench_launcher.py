@@ -116,3 +116,14 @@ def test_launcher_does_not_import_torch_or_touch_the_gpu():
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=120)
     assert p.returncode == 0 and b"ok" in p.stdout, p.stderr.decode()[-2000:]
+
+
+def test_every_tool_script_compiles():
+    """tools/*.py run on the GPU box only (sweeps, probes' drivers, the parity fuzzer): at least their syntax is checked here."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) >= 20
+    for f in files:
+        with open(f) as src:
+            compile(src.read(), f, "exec")
