@@ -82,7 +82,7 @@ def fuzz(cases, seed, out=sys.stdout):
     dev = torch.device("cuda:0")
     kernels = {"generic": pkg.KERNEL_GENERIC, "auto": pkg.KERNEL_AUTO, "tiled": pkg.KERNEL_TILED, "jit": pkg.KERNEL_JIT,
                "dense": pkg.KERNEL_DENSE}
-    ran, failed, by_name, lines, imports, chains = 0, 0, {}, [], 0, 0
+    ran, failed, by_name, lines, imports, chains, partial = 0, 0, {}, [], 0, 0, 0
 
     def report(line):
         lines.append(line)
@@ -159,6 +159,16 @@ def fuzz(cases, seed, out=sys.stdout):
                 plan.weight_align(w)
                 got = plan.forward(xd, bd).cpu().numpy()
                 name = plan.kernel_name
+                # ... and a call on FEWER images than the plan was created for (the reference's SCONV mode hands the layer one
+                # image at a time, conv_layer.cu:16-26): the same values for those images, bit for bit
+                if N > 1 and rng.randint(3) == 0:
+                    n_part = int(rng.randint(1, N))
+                    part = plan.forward(xd[:n_part].contiguous(), bd).cpu().numpy()
+                    partial += 1
+                    if part.shape[0] != n_part or not np.array_equal(part, got[:n_part]):
+                        report("FAIL partial batch %s via %s %s: %d of %d images differ from the full call (rel err %.3g) seed=%d k=%d" %
+                               (kn, name, tuple(s), n_part, N, rel_err(part, got[:n_part]), seed, k))
+                        failed += 1
             except Exception as e:
                 if kn in ("tiled", "jit") and "requested" in str(e):      # a forced kernel that does not cover the geometry says so
                     plan.close()
@@ -202,6 +212,7 @@ def fuzz(cases, seed, out=sys.stdout):
             print("# %d cases, %d runs, %d failures, %.0f s" % (k + 1, ran, failed, time.time() - t0), file=out, flush=True)
     by_name["(aligned forms handed to a fresh plan)"] = imports
     by_name["(math_functions-level drop-in chains)"] = chains
+    by_name["(calls on fewer images than the plan's batch)"] = partial
     return ran, lines, by_name
 
 
