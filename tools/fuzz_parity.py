@@ -82,7 +82,7 @@ def fuzz(cases, seed, out=sys.stdout):
     dev = torch.device("cuda:0")
     kernels = {"generic": pkg.KERNEL_GENERIC, "auto": pkg.KERNEL_AUTO, "tiled": pkg.KERNEL_TILED, "jit": pkg.KERNEL_JIT,
                "dense": pkg.KERNEL_DENSE}
-    ran, failed, by_name, lines, imports, chains, partial = 0, 0, {}, [], 0, 0, 0
+    ran, failed, by_name, lines, imports, chains, partial, modes = 0, 0, {}, [], 0, 0, 0, 0
 
     def report(line):
         lines.append(line)
@@ -147,8 +147,13 @@ def fuzz(cases, seed, out=sys.stdout):
                 opts["max_launch_bytes"] = mlb
             if kn == "auto" and rng.randint(2):
                 opts["dense_threshold_pct"] = 100         # keep AUTO on the sparse kernels
+            # Caffe::conv_mode (caffe.cpp -conv_mode): the four modes on the plan's own pick, one case in three
+            cmode = pkg.CONV_MODE_SCONV_PAR
+            if kn == "auto" and rng.randint(3) == 0:
+                cmode = int(rng.choice([pkg.CONV_MODE_LOWERED_GEMM, pkg.CONV_MODE_LOWERED_SPARSE, pkg.CONV_MODE_SCONV]))
+                modes += 1
             try:
-                plan = pkg.Plan(desc, kernel=kernel, **opts)
+                plan = pkg.Plan(desc, kernel=kernel, conv_mode=cmode, **opts)
             except Exception as e:      # a forced kernel that does not cover the geometry says so at plan creation
                 if kn in ("tiled", "jit"):
                     continue
@@ -213,6 +218,7 @@ def fuzz(cases, seed, out=sys.stdout):
     by_name["(aligned forms handed to a fresh plan)"] = imports
     by_name["(math_functions-level drop-in chains)"] = chains
     by_name["(calls on fewer images than the plan's batch)"] = partial
+    by_name["(plans in another Caffe::conv_mode)"] = modes
     return ran, lines, by_name
 
 
