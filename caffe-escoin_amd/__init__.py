@@ -6,8 +6,9 @@ in ``caffe_shim/``.  This Python module is only a ctypes binding of that C ABI, 
 tests and ``bench.py``; torch supplies device memory, streams and ``torch.distributed`` --
 plumbing, not the product.
 
-There is no CPU fallback: if the library is missing or no HIP device is visible the compute
-entry points raise.
+No silent CPU fallback: if the library is missing, or no HIP device is visible, the GPU entry
+points raise.  Caffe::CPU mode is its own explicit set of entry points (``Plan.weight_align_cpu`` /
+``Plan.forward_cpu``), implemented in the same library and usable without a GPU.
 """
 import ctypes as C
 import os
@@ -33,6 +34,14 @@ API_SYMBOLS = [
     "escoin_plan_export_aligned", "escoin_plan_import_aligned", "escoin_plan_stat",
     "escoin_gpu_sconv", "escoin_gpu_stretch", "escoin_copy_input_data",
     "escoin_gpu_sparse_dense2csr", "escoin_gpu_sparse_csrmm",
+    # Dtype = double
+    "escoin_weight_align_f64", "escoin_plan_set_csr_f64", "escoin_plan_get_csr_f64", "escoin_forward_f64",
+    "escoin_gpu_sconv_f64", "escoin_copy_input_data_f64", "escoin_gpu_sparse_csrmm_f64",
+    "escoin_gpu_sparse_dense2csr_f64",
+    # Caffe::CPU mode
+    "escoin_cpu_kernel_name", "escoin_weight_align_cpu", "escoin_weight_align_cpu_f64",
+    "escoin_forward_cpu", "escoin_forward_cpu_f64", "escoin_cpu_sconv", "escoin_cpu_sconv_f64",
+    "escoin_cpu_sparse_dense2csr", "escoin_cpu_sparse_dense2csr_f64",
 ]
 
 
@@ -121,6 +130,35 @@ def lib():
     L.escoin_gpu_sparse_dense2csr.argtypes = [ip, ip, vp, vp, vp, vp, vp, C.POINTER(ip), vp]
     L.escoin_gpu_sparse_csrmm.restype = ip
     L.escoin_gpu_sparse_csrmm.argtypes = [ip, ip, ip, ip, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp]
+    for suffix in ("", "_f64"):
+        real = C.c_float if suffix == "" else C.c_double
+        f = getattr(L, "escoin_weight_align_cpu" + suffix)
+        f.restype, f.argtypes = ip, [vp, vp]
+        f = getattr(L, "escoin_forward_cpu" + suffix)
+        f.restype, f.argtypes = ip, [vp, vp, vp, vp, ip, ip]
+        f = getattr(L, "escoin_cpu_sconv" + suffix)
+        f.restype, f.argtypes = ip, [vp] + [ip] * 9 + [vp, vp, vp, ip, ip, vp, vp, ip, ip]
+        f = getattr(L, "escoin_cpu_sparse_dense2csr" + suffix)
+        f.restype, f.argtypes = ip, [ip, ip, vp, vp, vp, vp]
+        if suffix:
+            L.escoin_weight_align_f64.restype = ip
+            L.escoin_weight_align_f64.argtypes = [vp, vp, ip, vp]
+            L.escoin_plan_set_csr_f64.restype = ip
+            L.escoin_plan_set_csr_f64.argtypes = [vp, vp, vp, vp, vp, vp]
+            L.escoin_plan_get_csr_f64.restype = ip
+            L.escoin_plan_get_csr_f64.argtypes = [vp, vp, vp, vp, ip]
+            L.escoin_forward_f64.restype = ip
+            L.escoin_forward_f64.argtypes = [vp, vp, vp, vp, ip, vp]
+            L.escoin_gpu_sconv_f64.restype = ip
+            L.escoin_gpu_sconv_f64.argtypes = L.escoin_gpu_sconv.argtypes
+            L.escoin_copy_input_data_f64.restype = ip
+            L.escoin_copy_input_data_f64.argtypes = L.escoin_copy_input_data.argtypes
+            L.escoin_gpu_sparse_dense2csr_f64.restype = ip
+            L.escoin_gpu_sparse_dense2csr_f64.argtypes = L.escoin_gpu_sparse_dense2csr.argtypes
+            L.escoin_gpu_sparse_csrmm_f64.restype = ip
+            L.escoin_gpu_sparse_csrmm_f64.argtypes = [ip, ip, ip, ip, real, vp, vp, vp, vp, real, vp, vp]
+    L.escoin_cpu_kernel_name.restype = cp
+    L.escoin_cpu_kernel_name.argtypes = []
     _lib = L
     return L
 
@@ -132,6 +170,11 @@ def check(rc, what="escoin call"):
 
 def device_count():
     return lib().escoin_device_count()
+
+
+def cpu_kernel_name():
+    """Which flavour of the host kernel Caffe::CPU mode runs on this machine."""
+    return lib().escoin_cpu_kernel_name().decode()
 
 
 def out_shape(desc):
@@ -175,23 +218,49 @@ class Plan(object):
               "escoin_plan_set_option(%s)" % key)
 
     def weight_align(self, dense_w, stream=None):
-        """WeightAlign().  dense_w: numpy (host) or torch CUDA tensor (device), M x C/g x KH x KW."""
+        """WeightAlign().  dense_w: numpy (host) or torch CUDA tensor (device), M x C/g x KH x KW;
+        float64 input makes a Dtype = double plan (escoin_weight_align_f64)."""
         if isinstance(dense_w, np.ndarray):
-            w = np.ascontiguousarray(dense_w, np.float32)
-            check(lib().escoin_weight_align(self._h, _np_ptr(w), 0, stream), "escoin_weight_align")
+            f64 = dense_w.dtype == np.float64
+            w = np.ascontiguousarray(dense_w, np.float64 if f64 else np.float32)
+            fn = lib().escoin_weight_align_f64 if f64 else lib().escoin_weight_align
+            check(fn(self._h, _np_ptr(w), 0, stream), "escoin_weight_align")
         else:
             w = dense_w.contiguous()
-            assert w.is_cuda and w.dtype.is_floating_point and w.element_size() == 4
-            check(lib().escoin_weight_align(self._h, C.c_void_p(w.data_ptr()), 1, stream),
-                  "escoin_weight_align")
+            assert w.is_cuda and w.dtype.is_floating_point and w.element_size() in (4, 8)
+            fn = lib().escoin_weight_align_f64 if w.element_size() == 8 else lib().escoin_weight_align
+            check(fn(self._h, C.c_void_p(w.data_ptr()), 1, stream), "escoin_weight_align")
+
+    # ---- Caffe::CPU mode (no device needed) ----------------------------------------------------
+    def weight_align_cpu(self, dense_w):
+        """WeightAlign() in CPU mode: host CSR only.  float32 or float64 numpy."""
+        f64 = dense_w.dtype == np.float64
+        w = np.ascontiguousarray(dense_w, np.float64 if f64 else np.float32)
+        fn = lib().escoin_weight_align_cpu_f64 if f64 else lib().escoin_weight_align_cpu
+        check(fn(self._h, _np_ptr(w)), "escoin_weight_align_cpu")
+
+    def forward_cpu(self, bottom, bias=None, n_threads=0):
+        """Forward_cpu on numpy arrays (float32 or float64, matching the aligned weights)."""
+        d = self.desc
+        f64 = bottom.dtype == np.float64
+        dt = np.float64 if f64 else np.float32
+        x = np.ascontiguousarray(bottom, dt)
+        assert tuple(x.shape[1:]) == (d.C, d.H, d.W), "bottom shape mismatch"
+        b = None if bias is None else np.ascontiguousarray(bias, dt)
+        top = np.empty((x.shape[0], d.M) + tuple(self.out_hw), dt)
+        fn = lib().escoin_forward_cpu_f64 if f64 else lib().escoin_forward_cpu
+        check(fn(self._h, _np_ptr(x), _np_ptr(b) if b is not None else None, _np_ptr(top), x.shape[0],
+                 int(n_threads)), "escoin_forward_cpu")
+        return top
 
     def set_csr(self, rowptr, colidx, values, nnz_per_group, stream=None):
         rp = np.ascontiguousarray(rowptr, np.int32)
         ci = np.ascontiguousarray(colidx, np.int32)
-        va = np.ascontiguousarray(values, np.float32)
+        f64 = isinstance(values, np.ndarray) and values.dtype == np.float64
+        va = np.ascontiguousarray(values, np.float64 if f64 else np.float32)
         ng = np.ascontiguousarray(nnz_per_group, np.int32)
-        check(lib().escoin_plan_set_csr(self._h, _np_ptr(rp), _np_ptr(ci), _np_ptr(va), _np_ptr(ng),
-                                        stream), "escoin_plan_set_csr")
+        fn = lib().escoin_plan_set_csr_f64 if f64 else lib().escoin_plan_set_csr
+        check(fn(self._h, _np_ptr(rp), _np_ptr(ci), _np_ptr(va), _np_ptr(ng), stream), "escoin_plan_set_csr")
 
     def nnz(self, group=-1):
         n = lib().escoin_plan_nnz(self._h, group)
@@ -203,11 +272,12 @@ class Plan(object):
         d = self.desc
         mg = d.M // d.group
         nnz = self.nnz()
+        f64 = self.stat("is_f64") == 1
         rp = np.zeros(d.group * (mg + 1), np.int32)
         ci = np.zeros(max(nnz, 1), np.int32)
-        va = np.zeros(max(nnz, 1), np.float32)
-        check(lib().escoin_plan_get_csr(self._h, _np_ptr(rp), _np_ptr(ci), _np_ptr(va),
-                                        int(stretched)), "escoin_plan_get_csr")
+        va = np.zeros(max(nnz, 1), np.float64 if f64 else np.float32)
+        fn = lib().escoin_plan_get_csr_f64 if f64 else lib().escoin_plan_get_csr
+        check(fn(self._h, _np_ptr(rp), _np_ptr(ci), _np_ptr(va), int(stretched)), "escoin_plan_get_csr")
         ng = np.array([self.nnz(g) for g in range(d.group)], np.int32)
         return rp, ci[:nnz], va[:nnz], ng
 
@@ -256,19 +326,24 @@ class Plan(object):
                                    C.c_void_p(top_ptr), int(n_images), stream), "escoin_forward")
 
     def forward(self, bottom, bias=None, top=None):
-        """Forward_gpu on torch CUDA tensors, on torch's current stream."""
+        """Forward_gpu on torch CUDA tensors (float32, or float64 for a double plan), on torch's current stream."""
         import torch
         d = self.desc
-        assert bottom.is_cuda and bottom.dtype == torch.float32 and bottom.is_contiguous()
+        dt = bottom.dtype
+        assert bottom.is_cuda and dt in (torch.float32, torch.float64) and bottom.is_contiguous()
         n = bottom.shape[0]
         assert tuple(bottom.shape[1:]) == (d.C, d.H, d.W), "bottom shape mismatch"
         if top is None:
-            top = torch.empty((n, d.M) + tuple(self.out_hw), device=bottom.device,
-                              dtype=torch.float32)
-        assert top.is_contiguous() and tuple(top.shape) == (n, d.M) + tuple(self.out_hw)
+            top = torch.empty((n, d.M) + tuple(self.out_hw), device=bottom.device, dtype=dt)
+        assert top.is_contiguous() and top.dtype == dt and tuple(top.shape) == (n, d.M) + tuple(self.out_hw)
         if bias is not None:
-            assert bias.is_cuda and bias.dtype == torch.float32 and bias.numel() == d.M
+            assert bias.is_cuda and bias.dtype == dt and bias.numel() == d.M
         stream = C.c_void_p(torch.cuda.current_stream(bottom.device).cuda_stream)
+        if dt == torch.float64:
+            check(lib().escoin_forward_f64(self._h, C.c_void_p(bottom.data_ptr()),
+                                           C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                           C.c_void_p(top.data_ptr()), int(n), stream), "escoin_forward_f64")
+            return top
         self.forward_ptr(bottom.data_ptr(), bias.data_ptr() if bias is not None else 0,
                          top.data_ptr(), n, stream)
         return top

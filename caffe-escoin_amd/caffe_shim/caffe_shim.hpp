@@ -1,5 +1,5 @@
 // caffe_shim.hpp -- header-only mirror of the slice of Caffe's C++ API that the sparse
-// convolution path sits behind, so that ConvolutionLayer<float> below could be pasted into a
+// convolution path sits behind, so that ConvolutionLayer<Dtype> below could be pasted into a
 // Caffe-HIP tree: same class names, method names, argument meaning and (fatal) error behaviour
 // as the reference.  It is NOT Caffe: only what the hot path touches exists.
 //
@@ -12,13 +12,16 @@
 //   caffe::ConvolutionLayer      include/caffe/layers/conv_layer.hpp:30-80, conv_layer.cu:8-40
 //   caffe::ConvolutionReLULayer  include/caffe/layers/conv_relu_layer.hpp, conv_relu_layer.cu:8-30
 //
-// Forward_gpu calls the C ABI (include/escoin.h).  There is no CPU path: Forward_cpu aborts,
-// exactly like NOT_IMPLEMENTED (common.hpp:70) does.
+// Forward_gpu and Forward_cpu both call the C ABI (include/escoin.h): Caffe::GPU mode runs the HIP kernels,
+// Caffe::CPU mode the library's host kernel (escoin_forward_cpu; no device is touched, so a CPU-mode net runs on a
+// machine without a GPU).  Every class is a template over Dtype = float | double like the reference's
+// (INSTANTIATE_CLASS, conv_layer.cpp:102): EscApi<Dtype> below maps the type to the C entry points.
 #ifndef ESCOIN_CAFFE_SHIM_HPP_
 #define ESCOIN_CAFFE_SHIM_HPP_
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,12 +84,32 @@ class Caffe {
   static void set_conv_mode(ConvMode m) { Get().conv_mode_ = m; }    // common.hpp:161
   static void SetDevice(int device_id) { ESC_HIP_CHECK(hipSetDevice(device_id)); }
   static hipStream_t stream() { return nullptr; }   // every reference launch uses stream 0
+  // host threads of CPU mode (0 = all the process may run on): the reference takes OMP_NUM_THREADS for its ICC build's
+  // batch loop (conv_layer.cpp:41-43); there is no OpenMP runtime here, so the number is a setting
+  static int cpu_threads() { return Get().cpu_threads_; }
+  static void set_cpu_threads(int n) { Get().cpu_threads_ = n; }
 
  private:
   // the reference leaves conv_mode_ uninitialised; here it defaults to SCONV_PAR
-  Caffe() : mode_(CPU), conv_mode_(SCONV_PAR) {}
+  Caffe() : mode_(CPU), conv_mode_(SCONV_PAR), cpu_threads_(0) {}
   Brew mode_;
   ConvMode conv_mode_;
+  int cpu_threads_;
+};
+
+// Dtype -> C ABI.  The float entry points are the unsuffixed ones, double the _f64 twins (include/escoin.h).
+template <typename Dtype> struct EscApi;
+template <> struct EscApi<float> {
+  static int weight_align(escoin_plan *p, const float *w, int on_dev, void *s) { return escoin_weight_align(p, w, on_dev, s); }
+  static int weight_align_cpu(escoin_plan *p, const float *w) { return escoin_weight_align_cpu(p, w); }
+  static int forward(escoin_plan *p, const float *b, const float *bias, float *t, int n, void *s) { return escoin_forward(p, b, bias, t, n, s); }
+  static int forward_cpu(escoin_plan *p, const float *b, const float *bias, float *t, int n, int threads) { return escoin_forward_cpu(p, b, bias, t, n, threads); }
+};
+template <> struct EscApi<double> {
+  static int weight_align(escoin_plan *p, const double *w, int on_dev, void *s) { return escoin_weight_align_f64(p, w, on_dev, s); }
+  static int weight_align_cpu(escoin_plan *p, const double *w) { return escoin_weight_align_cpu_f64(p, w); }
+  static int forward(escoin_plan *p, const double *b, const double *bias, double *t, int n, void *s) { return escoin_forward_f64(p, b, bias, t, n, s); }
+  static int forward_cpu(escoin_plan *p, const double *b, const double *bias, double *t, int n, int threads) { return escoin_forward_cpu_f64(p, b, bias, t, n, threads); }
 };
 
 // syncedmem.hpp:56-91: lazily mirrored host/device buffer with a head state.
@@ -227,10 +250,12 @@ class Layer {   // layer.hpp:33-475
       ESC_HIP_CHECK(hipEventCreate(&e1));
       ESC_HIP_CHECK(hipEventRecord(e0, Caffe::stream()));
     }
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     switch (Caffe::mode()) {
       case Caffe::CPU: Forward_cpu(bottom, top); break;
       case Caffe::GPU: Forward_gpu(bottom, top); break;
     }
+    if (!gpu) test_time_ = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
     if (gpu) {
       ESC_HIP_CHECK(hipEventRecord(e1, Caffe::stream()));
       ESC_HIP_CHECK(hipEventSynchronize(e1));
@@ -325,10 +350,16 @@ class BaseConvolutionLayer : public Layer<Dtype> {   // base_conv_layer.hpp:20-2
     // (base_conv_layer.cpp:49-53); here every mode is served from the aligned plan.
     ESCOIN_CHECK(escoin_plan_set_option(plan_, "conv_mode", (int)Caffe::conv_mode()));
     aligned_mode_ = Caffe::conv_mode();
-    if (Caffe::mode() == Caffe::GPU)
-      ESCOIN_CHECK(escoin_weight_align(plan_, this->blobs_[0]->gpu_data(), 1, Caffe::stream()));
-    else
-      ESCOIN_CHECK(escoin_weight_align(plan_, this->blobs_[0]->cpu_data(), 0, Caffe::stream()));
+    // GPU mode: CSR + the device weight streams / generated code (CSR branch of base_conv_layer.cpp:109-273).
+    // CPU mode: the host CSR only (:46-107) -- no device is touched; a later Forward in GPU mode aligns the device
+    // side on the spot (forward_gpu_sconv_par below).
+    if (Caffe::mode() == Caffe::GPU) {
+      ESCOIN_CHECK(EscApi<Dtype>::weight_align(plan_, this->blobs_[0]->gpu_data(), 1, Caffe::stream()));
+      aligned_on_device_ = true;
+    } else {
+      ESCOIN_CHECK(EscApi<Dtype>::weight_align_cpu(plan_, this->blobs_[0]->cpu_data()));
+      aligned_on_device_ = false;
+    }
     aligned_ = true;
   }
 
@@ -352,6 +383,7 @@ class BaseConvolutionLayer : public Layer<Dtype> {   // base_conv_layer.hpp:20-2
     aligned_mode_ = Caffe::conv_mode();
     ESCOIN_CHECK(escoin_plan_import_aligned(plan_, blob.data(), blob.size(), Caffe::stream()));
     aligned_ = true;
+    aligned_on_device_ = true;
     return escoin_plan_stat(plan_, "import_fast") == 1;
   }
 
@@ -359,7 +391,10 @@ class BaseConvolutionLayer : public Layer<Dtype> {   // base_conv_layer.hpp:20-2
   virtual inline int MinTopBlobs() const { return 1; }
   virtual inline bool EqualNumBottomTopBlobs() const { return true; }
   long nnz() const { return plan_ ? escoin_plan_nnz(plan_, -1) : 0; }
-  const char *kernel_name() const { return plan_ ? escoin_plan_kernel_name(plan_) : ""; }
+  const char *kernel_name() const {
+    if (Caffe::mode() == Caffe::CPU) return escoin_cpu_kernel_name();
+    return plan_ ? escoin_plan_kernel_name(plan_) : "";
+  }
 
  protected:
   escoin_conv_desc desc(const Blob<Dtype> *b, const ConvolutionParameter &cp) const {
@@ -374,16 +409,27 @@ class BaseConvolutionLayer : public Layer<Dtype> {   // base_conv_layer.hpp:20-2
   // forward_gpu_sconv_par + forward_gpu_bias (base_conv_layer.cpp:800-856) for the whole batch
   void forward_gpu_sconv_par(const Dtype *input, const Dtype * /*weights*/, Dtype *output) {
     ESC_CHECK(aligned_);   // the reference silently computes zeros here
+    if (!aligned_on_device_) {   // WeightAlign ran in CPU mode, the net was switched to GPU mode afterwards
+      ESCOIN_CHECK(EscApi<Dtype>::weight_align(plan_, this->blobs_[0]->gpu_data(), 1, Caffe::stream()));
+      aligned_on_device_ = true;
+    }
     if (Caffe::conv_mode() != aligned_mode_) {   // `caffe test -conv_mode N` flipped after the load
       ESCOIN_CHECK(escoin_plan_set_option(plan_, "conv_mode", (int)Caffe::conv_mode()));
       aligned_mode_ = Caffe::conv_mode();
     }
     const Dtype *bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
-    ESCOIN_CHECK(escoin_forward(plan_, input, bias, output, num_, Caffe::stream()));
+    ESCOIN_CHECK(EscApi<Dtype>::forward(plan_, input, bias, output, num_, Caffe::stream()));
+  }
+  // Forward_cpu's body for one bottom/top pair: the batch loop of conv_layer.cpp:44-61 (forward_cpu_sconv per image,
+  // base_conv_layer.cpp:569-661, then forward_cpu_bias, :663-669) inside the library, on Caffe::cpu_threads() threads
+  void forward_cpu_sconv_batch(const Dtype *input, Dtype *output) {
+    ESC_CHECK(aligned_);
+    const Dtype *bias = bias_term_ ? this->blobs_[1]->cpu_data() : nullptr;
+    ESCOIN_CHECK(EscApi<Dtype>::forward_cpu(plan_, input, bias, output, num_, Caffe::cpu_threads()));
   }
   escoin_plan *plan_;
   escoin_conv_desc desc_;
-  bool aligned_ = false;
+  bool aligned_ = false, aligned_on_device_ = false;
   Caffe::ConvMode aligned_mode_ = Caffe::SCONV_PAR;
   int num_, channels_, group_, num_output_;
   bool bias_term_, fuse_relu_;
@@ -398,8 +444,14 @@ class ConvolutionLayer : public BaseConvolutionLayer<Dtype> {   // conv_layer.hp
   virtual inline const char *type() const { return "Convolution"; }
 
  protected:
-  virtual void Forward_cpu(const vector<Blob<Dtype> *> &, const vector<Blob<Dtype> *> &) {
-    NOT_IMPLEMENTED;   // this build has no CPU path; the reference's lives in conv_layer.cpp:25-63
+  // conv_layer.cpp:25-63.  Every Caffe::ConvMode takes the direct sparse host kernel (the reference's Forward_cpu
+  // uses it for SCONV and the dense GEMM otherwise: same sums, escoin.h "Caffe::CPU mode").
+  virtual void Forward_cpu(const vector<Blob<Dtype> *> &bottom, const vector<Blob<Dtype> *> &top) {
+    for (size_t i = 0; i < bottom.size(); ++i) {
+      const Dtype *bottom_data = bottom[i]->cpu_data();
+      Dtype *top_data = top[i]->mutable_cpu_data();
+      this->forward_cpu_sconv_batch(bottom_data, top_data);
+    }
   }
   // conv_layer.cu:8-40.  SCONV and SCONV_PAR produce the same numbers; both go through one
   // batched launch per bottom (the per-image launches of SCONV are a reference artefact).

@@ -542,6 +542,15 @@ static int dense_device_cus() {
 }
 int dense_spare_rows() { return 128; }
 
+// Layers whose launches may split K across workgroups (launch_dense decides per batch): pointwise, stride 1, at least
+// eight k-steps -- or whatever ESCOIN_DENSE_STREAMK=1 forces in the experiments flavour.
+static bool dense_streamk_eligible(const Geometry &g) {
+  static const int sk_env = (int)ESC_KNOB("DENSE_STREAMK", -1);
+  if (sk_env >= 0) return sk_env != 0;
+  const long nk = (g.kdim + kBK - 1) / kBK;
+  return g.d.KH == 1 && g.d.KW == 1 && g.d.stride_h == 1 && g.d.stride_w == 1 && nk >= 8;
+}
+
 // The im2col decode of every k (one table per layer, built in WeightAlign): element offset of tap
 // (ic, kr, kc) relative to the top-left input element of an output pixel's window, and (dy, dx)
 // for the border test.  Entries past K (the last k-step) can never pass the test.
@@ -566,6 +575,27 @@ int dense_build_ktab(escoin_plan *p, hipStream_t stream) {
   p->device_bytes += sizeof(int) * tab.size();
   ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_ktab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, stream));
   ESCOIN_HIP_TRY(hipStreamSynchronize(stream));
+  // Stream-K workspace, here and not at the first launch: escoin_forward must neither allocate nor synchronise (a host
+  // may capture its very first forward into a HIP graph).  A stream-K launch always runs
+  // 2 x CUs workgroups whatever the batch, so the size is known now: the flag words, then 64 KB of partial
+  // accumulators per workgroup (32 MB on an MI355X), plus the pinned host word a give-up is reported through.  Only
+  // for layers launch_dense can ever split (dense_streamk_eligible).
+  if (dense_streamk_eligible(g)) {
+    const long n_wg = 2l * dense_device_cus();
+    const size_t ws_bytes = (size_t)n_wg * 4 * 16 * 64 * 4 * sizeof(float);
+    const size_t flag_bytes = ((size_t)(n_wg + 1) * 4 + 15) / 16 * 16;
+    if (!p->h_sk_fail) ESCOIN_HIP_TRY(hipHostMalloc((void **)&p->h_sk_fail, 64, hipHostMallocMapped));
+    *p->h_sk_fail = 0u;
+    ESCOIN_HIP_TRY(hipHostGetDevicePointer((void **)&p->d_sk_fail, p->h_sk_fail, 0));
+    if (p->d_sk_ws) (void)hipFree(p->d_sk_ws);
+    p->d_sk_ws = nullptr;
+    p->sk_ws_bytes = 0;
+    ESCOIN_HIP_TRY(hipMalloc(&p->d_sk_ws, ws_bytes + flag_bytes));
+    p->sk_ws_bytes = ws_bytes + flag_bytes;
+    p->device_bytes += ws_bytes + flag_bytes;
+    ESCOIN_HIP_TRY(hipMemset(p->d_sk_ws, 0, flag_bytes));
+    p->sk_flag_words = (int)n_wg + 1;
+  }
   return ESCOIN_OK;
 }
 
@@ -640,33 +670,23 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   const bool unit_1x1 = g.d.KH == 1 && g.d.KW == 1 && g.d.stride_h == 1 && g.d.stride_w == 1;
   bool streamk = sk_env >= 0 ? sk_env != 0 : (unit_1x1 && occupancy < 0.85 && nk >= 8 && tiles * nk >= 4 * slots);
   if (tiles * nk < slots || strided1) streamk = false;
+  // (the workspace and the pinned give-up word were allocated by dense_build_ktab at WeightAlign; a launch never
+  //  allocates -- a plan without them runs whole tiles)
+  if (streamk && (!p->d_sk_ws || !p->h_sk_fail || !p->d_sk_fail ||
+                  p->sk_ws_bytes < (size_t)slots * 4 * 16 * 64 * 4 * sizeof(float) + ((size_t)(slots + 1) * 4 + 15) / 16 * 16))
+    streamk = false;
   const long n_wg = streamk ? slots : std::min<long>(tiles, slots);
   a.sk_ws = nullptr;
   a.sk_flag = nullptr;
   a.sk_fail = nullptr;
   if (streamk) {
-    if (!p->h_sk_fail) {
-      // one word of pinned, device-visible host memory per plan: a give-up in ANY launch stays there, and
-      // escoin_forward reads it without synchronising (escoin_capi.hip)
-      ESCOIN_HIP_TRY(hipHostMalloc((void **)&p->h_sk_fail, 64, hipHostMallocMapped));
-      *p->h_sk_fail = 0u;
-    }
-    ESCOIN_HIP_TRY(hipHostGetDevicePointer((void **)&a.sk_fail, p->h_sk_fail, 0));
-    const size_t ws_bytes = (size_t)n_wg * 4 * 16 * 64 * 4 * sizeof(float);
+    a.sk_fail = p->d_sk_fail;
     const size_t flag_bytes = ((size_t)(n_wg + 1) * 4 + 15) / 16 * 16;
-    if (p->sk_ws_bytes < ws_bytes + flag_bytes) {
-      if (p->d_sk_ws) (void)hipFree(p->d_sk_ws);
-      p->d_sk_ws = nullptr;
-      p->sk_ws_bytes = 0;
-      // (the flag block leads: it is what the memset below clears, from the allocation's start, a multiple of 16 bytes)
-      ESCOIN_HIP_TRY(hipMalloc(&p->d_sk_ws, ws_bytes + flag_bytes));
-      p->sk_ws_bytes = ws_bytes + flag_bytes;
-    }
     a.sk_flag = reinterpret_cast<unsigned *>(p->d_sk_ws);
     a.sk_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(p->d_sk_ws) + flag_bytes);
     ESCOIN_HIP_TRY(hipMemsetAsync(a.sk_flag, 0, flag_bytes, stream));
-    p->sk_flag_words = (int)n_wg + 1;
   }
+  p->sk_used = streamk;
   dim3 grid((unsigned)n_wg, 1, 1);
 #define ESC_DENSE_LAUNCH(WR, MODE)                                                                                 \
   do {                                                                                                             \

@@ -28,26 +28,15 @@ int fail(int code, const std::string &msg) {
 constexpr int kDefaultDenseThresholdPct = 50;
 constexpr int kGenericDenseThresholdPct = 4;
 
-// No exception may cross the C ABI (std::bad_alloc from the host vectors, std::system_error from a thread pool):
-// every entry point that allocates runs its body through this.
-template <typename F>
-static int guarded(F &&body) {
-  try {
-    return body();
-  } catch (const std::bad_alloc &) {
-    return fail(ESCOIN_ENOMEM, "out of host memory");
-  } catch (const std::exception &e) {
-    return fail(ESCOIN_EINVAL, std::string("internal error: ") + e.what());
-  } catch (...) {
-    return fail(ESCOIN_EINVAL, "internal error");
-  }
-}
-
 static double ms_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-int set_csr_host(escoin_plan *p, const int *rowptr, const int *colidx, const float *values, const int *nnz_per_group);
+template <typename T>
+int set_csr_host(escoin_plan *p, const int *rowptr, const int *colidx, const T *values, const int *nnz_per_group);
+template <typename T> std::vector<std::vector<T>> &plan_vals(escoin_plan *p);
+template <> std::vector<std::vector<float>> &plan_vals<float>(escoin_plan *p) { return p->values; }
+template <> std::vector<std::vector<double>> &plan_vals<double>(escoin_plan *p) { return p->values64; }
 
 static int out_dim(int in, int k, int pad, int stride, int dil) {
   // conv_layer.cpp:16-19
@@ -84,6 +73,8 @@ static void free_device(escoin_plan *p) {
   if (p->d_rowptr) (void)hipFree(p->d_rowptr);
   if (p->d_taps) (void)hipFree(p->d_taps);
   if (p->d_vals) (void)hipFree(p->d_vals);
+  if (p->d_vals64) (void)hipFree(p->d_vals64);
+  p->d_vals64 = nullptr;
   tiled_release(p);
   if (p->d_col) (void)hipFree(p->d_col);
   p->d_col = nullptr;
@@ -98,9 +89,53 @@ static void free_device(escoin_plan *p) {
   p->sk_flag_words = 0;
   if (p->h_sk_fail) (void)hipHostFree(p->h_sk_fail);
   p->h_sk_fail = nullptr;
+  p->d_sk_fail = nullptr;
+  p->sk_used = false;
   p->d_rowptr = p->d_taps = nullptr;
   p->d_vals = nullptr;
   p->device_bytes = 0;
+}
+
+// Dtype = double: rowptr / packed taps / double values for the order-preserving generic kernel -- the only device
+// kernel a double plan runs, in every conv_mode (fp64 vector FMA is native on gfx950; the LDS-tiled, generated-code and
+// MFMA kernels are fp32: north_star measures fp32, double is boundary completeness, conv_layer.cu:75).
+static int upload_f64(escoin_plan *p, hipStream_t stream) {
+  const Geometry &g = p->g;
+  long nnz = 0;
+  for (int grp = 0; grp < g.d.group; ++grp) nnz += (long)p->colidx[grp].size();
+  std::vector<int> rowptr(g.d.M + 1), taps((size_t)(nnz > 0 ? nnz : 1));
+  std::vector<double> vals((size_t)(nnz > 0 ? nnz : 1));
+  long base = 0;
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    for (int m = 0; m < g.Mg; ++m) rowptr[grp * g.Mg + m] = (int)(base + p->rowptr[grp][m]);
+    const long n_g = (long)p->colidx[grp].size();
+    for (long j = 0; j < n_g; ++j) {
+      const int col = p->colidx[grp][j];
+      taps[base + j] = pack_tap(col / (g.d.KW * g.d.KH), (col / g.d.KW) % g.d.KH, col % g.d.KW);
+      vals[base + j] = p->values64[grp][j];
+    }
+    base += n_g;
+  }
+  rowptr[g.d.M] = (int)base;
+  ESCOIN_HIP_TRY(hipMalloc(&p->d_rowptr, sizeof(int) * rowptr.size()));
+  ESCOIN_HIP_TRY(hipMalloc(&p->d_taps, sizeof(int) * taps.size()));
+  ESCOIN_HIP_TRY(hipMalloc(&p->d_vals64, sizeof(double) * vals.size()));
+  p->device_bytes += sizeof(int) * (rowptr.size() + taps.size()) + sizeof(double) * vals.size();
+  ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_rowptr, rowptr.data(), sizeof(int) * rowptr.size(), hipMemcpyHostToDevice, stream));
+  ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_taps, taps.data(), sizeof(int) * taps.size(), hipMemcpyHostToDevice, stream));
+  ESCOIN_HIP_TRY(hipMemcpyAsync(p->d_vals64, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice, stream));
+  ESCOIN_HIP_TRY(hipStreamSynchronize(stream));  // host vectors die at scope exit
+  p->tiled = TiledConfig();
+  p->n_dense_groups = 0;
+  p->n_sparse_groups = g.d.group;
+  p->use_dense = false;
+  p->dense_mask = 0;
+  p->sparse_mask = ~0ull;
+  p->small_rule = 0;
+  p->import_fast = false;
+  p->kernel_name = generic_kernel_name_f64(g.d.fuse_relu != 0);
+  p->aligned = true;
+  return ESCOIN_OK;
 }
 
 // Uploads the CSR held in p->rowptr/colidx/values and builds the kernel-specific
@@ -110,9 +145,10 @@ static void free_device(escoin_plan *p) {
 static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nullptr, size_t jit_blob_bytes = 0) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-    return fail(ESCOIN_ENODEVICE, "no HIP device: this library has no CPU fallback");
+    return fail(ESCOIN_ENODEVICE, "no HIP device: escoin_weight_align / set_csr / import_aligned prepare the GPU path (Caffe::CPU mode has its own entry points: escoin_weight_align_cpu, escoin_forward_cpu)");
   ESCOIN_HIP_TRY(hipGetDevice(&p->device));
   free_device(p);
+  if (p->is_f64) return upload_f64(p, stream);
   const Geometry &g = p->g;
   long nnz = 0;
   for (int grp = 0; grp < g.d.group; ++grp) nnz += (long)p->colidx[grp].size();
@@ -338,6 +374,104 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
   return ESCOIN_OK;
 }
 
+
+template <typename T>
+void csr_from_dense(escoin_plan *p, const T *w) {
+  const Geometry &g = p->g;
+  // caffe_cpu_sparse_dense2csr, math_functions.cpp:92-105: row-major scan, keep != 0
+  const size_t weight_offset = (size_t)g.Mg * g.kdim;  // base_conv_layer.cpp:60
+  p->aligned = false;
+  p->host_aligned = false;
+  free_device(p);
+  p->is_f64 = sizeof(T) == 8;
+  std::vector<std::vector<T>> &vals = plan_vals<T>(p);
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    std::vector<int> &rp = p->rowptr[grp];
+    std::vector<int> &ci = p->colidx[grp];
+    std::vector<T> &va = vals[grp];
+    rp.assign(g.Mg + 1, 0);
+    ci.clear();
+    va.clear();
+    p->values[grp].clear();
+    p->values64[grp].clear();
+    const T *A = w + weight_offset * grp;
+    for (int i = 0; i < g.Mg; ++i) {
+      for (int j = 0; j < g.kdim; ++j) {
+        const T v = A[(size_t)i * g.kdim + j];
+        if (v != 0) {
+          va.push_back(v);
+          ci.push_back(j);
+        }
+      }
+      rp[i + 1] = (int)ci.size();
+    }
+  }
+  p->cpu_off_valid = false;
+  p->host_aligned = true;
+}
+template void csr_from_dense<float>(escoin_plan *, const float *);
+template void csr_from_dense<double>(escoin_plan *, const double *);
+
+template <typename T>
+static int weight_align_t(escoin_plan *p, const T *dense_w, int w_on_device, void *stream) {
+  if (!p || !dense_w) return fail(ESCOIN_EINVAL, "null argument");
+  const auto t_start = std::chrono::steady_clock::now();
+  const Geometry &g = p->g;
+  const size_t count = (size_t)g.d.M * g.kdim;
+  std::vector<T> host;
+  const T *w = dense_w;
+  if (w_on_device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+      return fail(ESCOIN_ENODEVICE, "no HIP device: cannot read device weights");
+    host.resize(count);
+    ESCOIN_HIP_TRY(hipMemcpyAsync(host.data(), dense_w, sizeof(T) * count, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ESCOIN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    w = host.data();
+  }
+  csr_from_dense<T>(p, w);
+  const int rc = upload(p, (hipStream_t)stream);
+  p->align_ms = ms_since(t_start);
+  return rc;
+}
+
+template <typename T>
+static int set_csr_t(escoin_plan *p, const int *rowptr, const int *colidx, const T *values, const int *nnz_per_group,
+                     void *stream) {
+  const auto t_start = std::chrono::steady_clock::now();
+  const int rc = set_csr_host<T>(p, rowptr, colidx, values, nnz_per_group);
+  if (rc != ESCOIN_OK) return rc;
+  const int rc2 = upload(p, (hipStream_t)stream);
+  p->align_ms = ms_since(t_start);
+  return rc2;
+}
+
+template <typename T>
+static int get_csr_t(const escoin_plan *p, int *rowptr, int *colidx, T *values, int stretched) {
+  if (!p || !rowptr) return fail(ESCOIN_EINVAL, "null argument");
+  if (values && p->host_aligned && p->is_f64 != (sizeof(T) == 8))
+    return fail(ESCOIN_ESTATE, p->is_f64 ? "get_csr: the plan holds double values (use escoin_plan_get_csr_f64)"
+                                         : "get_csr_f64: the plan holds float values (use escoin_plan_get_csr)");
+  const Geometry &g = p->g;
+  const std::vector<std::vector<T>> &vals = plan_vals<T>(const_cast<escoin_plan *>(p));
+  long base = 0;
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    memcpy(rowptr + (size_t)grp * (g.Mg + 1), p->rowptr[grp].data(), sizeof(int) * (g.Mg + 1));
+    const long n_g = (long)p->colidx[grp].size();
+    for (long j = 0; j < n_g; ++j) {
+      int col = p->colidx[grp][j];
+      if (stretched) {  // base_conv_layer.cpp:99-105
+        const int kc = col % g.d.KW, kr = (col / g.d.KW) % g.d.KH, ic = col / (g.d.KW * g.d.KH);
+        col = (ic * (g.d.H + g.d.pad_h) + kr) * (g.d.W + g.d.pad_w) + kc;
+      }
+      if (colidx) colidx[base + j] = col;
+      if (values) values[base + j] = vals[grp][j];
+    }
+    base += n_g;
+  }
+  return ESCOIN_OK;
+}
+
 }  // namespace escoin
 
 using namespace escoin;
@@ -363,8 +497,12 @@ int escoin_out_shape(const escoin_conv_desc *desc, int *out_h, int *out_w) {
 
 long escoin_padded_len(const escoin_conv_desc *d) {
   if (!d) return fail(ESCOIN_EINVAL, "null descriptor");
-  // base_conv_layer.cpp:71
-  return (long)d->C * (d->H + d->pad_h) * (d->W + d->pad_w) + (long)d->pad_h * (d->W + 2 * d->pad_w);
+  // base_conv_layer.cpp:71, plus the pad_w floats that formula forgets when pad_h == 0 < pad_w: the last row's right
+  // padding is read out of the floats that follow the row, and without a bottom padding row nothing follows the last
+  // channel's last row (the reference's kernels read past its allocation there; none of its models has such a layer).
+  // A buffer of this length, zeroed once, is safe for every entry point of this library.
+  return (long)d->C * (d->H + d->pad_h) * (d->W + d->pad_w) + (long)d->pad_h * (d->W + 2 * d->pad_w) +
+         (d->pad_h == 0 ? d->pad_w : 0);
 }
 
 int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan) {
@@ -380,6 +518,7 @@ int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan) {
     p->rowptr.assign(g.d.group, std::vector<int>(g.Mg + 1, 0));
     p->colidx.assign(g.d.group, std::vector<int>());
     p->values.assign(g.d.group, std::vector<float>());
+    p->values64.assign(g.d.group, std::vector<double>());
     *plan = p;
     return ESCOIN_OK;
   });
@@ -448,69 +587,30 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
 }
 
 int escoin_weight_align(escoin_plan *p, const float *dense_w, int w_on_device, void *stream) {
-  return guarded([&]() -> int {
-    if (!p || !dense_w) return fail(ESCOIN_EINVAL, "null argument");
-    const auto t_start = std::chrono::steady_clock::now();
-    const Geometry &g = p->g;
-    const size_t count = (size_t)g.d.M * g.kdim;
-    std::vector<float> host;
-    const float *w = dense_w;
-    if (w_on_device) {
-      int ndev = 0;
-      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return fail(ESCOIN_ENODEVICE, "no HIP device: cannot read device weights");
-      host.resize(count);
-      ESCOIN_HIP_TRY(hipMemcpyAsync(host.data(), dense_w, sizeof(float) * count,
-                                    hipMemcpyDeviceToHost, (hipStream_t)stream));
-      ESCOIN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-      w = host.data();
-    }
-    // caffe_cpu_sparse_dense2csr, math_functions.cpp:92-105: row-major scan, keep != 0
-    const size_t weight_offset = (size_t)g.Mg * g.kdim;  // base_conv_layer.cpp:60
-    for (int grp = 0; grp < g.d.group; ++grp) {
-      std::vector<int> &rp = p->rowptr[grp];
-      std::vector<int> &ci = p->colidx[grp];
-      std::vector<float> &va = p->values[grp];
-      rp.assign(g.Mg + 1, 0);
-      ci.clear();
-      va.clear();
-      const float *A = w + weight_offset * grp;
-      for (int i = 0; i < g.Mg; ++i) {
-        for (int j = 0; j < g.kdim; ++j) {
-          const float v = A[(size_t)i * g.kdim + j];
-          if (v != 0) {
-            va.push_back(v);
-            ci.push_back(j);
-          }
-        }
-        rp[i + 1] = (int)ci.size();
-      }
-    }
-    p->aligned = false;
-    const int rc = upload(p, (hipStream_t)stream);
-    p->align_ms = ms_since(t_start);
-    return rc;
-  });
+  return guarded([&]() -> int { return weight_align_t<float>(p, dense_w, w_on_device, stream); });
+}
+
+int escoin_weight_align_f64(escoin_plan *p, const double *dense_w, int w_on_device, void *stream) {
+  return guarded([&]() -> int { return weight_align_t<double>(p, dense_w, w_on_device, stream); });
 }
 
 int escoin_plan_set_csr(escoin_plan *p, const int *rowptr, const int *colidx, const float *values,
                         const int *nnz_per_group, void *stream) {
-  return guarded([&]() -> int {
-    const auto t_start = std::chrono::steady_clock::now();
-    const int rc = set_csr_host(p, rowptr, colidx, values, nnz_per_group);
-    if (rc != ESCOIN_OK) return rc;
-    p->aligned = false;
-    const int rc2 = upload(p, (hipStream_t)stream);
-    p->align_ms = ms_since(t_start);
-    return rc2;
-  });
+  return guarded([&]() -> int { return set_csr_t<float>(p, rowptr, colidx, values, nnz_per_group, stream); });
+}
+
+int escoin_plan_set_csr_f64(escoin_plan *p, const int *rowptr, const int *colidx, const double *values,
+                            const int *nnz_per_group, void *stream) {
+  return guarded([&]() -> int { return set_csr_t<double>(p, rowptr, colidx, values, nnz_per_group, stream); });
 }
 
 }  // extern "C"
 
 namespace escoin {
-// Validates a CSR and copies it into the plan's host vectors (shared by set_csr and import_aligned).
-int set_csr_host(escoin_plan *p, const int *rowptr, const int *colidx, const float *values, const int *nnz_per_group) {
+// Validates a CSR and copies it into the plan's host vectors (shared by set_csr and import_aligned); fixes the plan's
+// Dtype like a WeightAlign does.
+template <typename T>
+int set_csr_host(escoin_plan *p, const int *rowptr, const int *colidx, const T *values, const int *nnz_per_group) {
   if (!p || !rowptr || !nnz_per_group) return fail(ESCOIN_EINVAL, "null argument");
   const Geometry &g = p->g;
   long base = 0;
@@ -532,13 +632,30 @@ int set_csr_host(escoin_plan *p, const int *rowptr, const int *colidx, const flo
       for (int j = rp[m] + 1; j < rp[m + 1]; ++j)
         if (colidx[base + j] <= colidx[base + j - 1])
           return fail(ESCOIN_EINVAL, "set_csr: column indices must be strictly ascending within a row");
-    p->rowptr[grp].assign(rp, rp + g.Mg + 1);
-    p->colidx[grp].assign(colidx + base, colidx + base + n_g);
-    p->values[grp].assign(values + base, values + base + n_g);
     base += n_g;
   }
+  // (validated as a whole first: a refused CSR leaves the plan as it was)
+  p->aligned = false;
+  p->host_aligned = false;
+  p->is_f64 = sizeof(T) == 8;
+  std::vector<std::vector<T>> &vals = plan_vals<T>(p);
+  base = 0;
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    const int n_g = nnz_per_group[grp];
+    const int *rp = rowptr + (size_t)grp * (g.Mg + 1);
+    p->rowptr[grp].assign(rp, rp + g.Mg + 1);
+    p->colidx[grp].assign(colidx + base, colidx + base + n_g);
+    p->values[grp].clear();
+    p->values64[grp].clear();
+    vals[grp].assign(values + base, values + base + n_g);
+    base += n_g;
+  }
+  p->cpu_off_valid = false;
+  p->host_aligned = true;
   return ESCOIN_OK;
 }
+template int set_csr_host<float>(escoin_plan *, const int *, const int *, const float *, const int *);
+template int set_csr_host<double>(escoin_plan *, const int *, const int *, const double *, const int *);
 }  // namespace escoin
 
 extern "C" {
@@ -557,6 +674,7 @@ int escoin_plan_export_aligned(const escoin_plan *p, void *buf, size_t capacity,
   return guarded([&]() -> int {
     if (!p || !bytes) return fail(ESCOIN_EINVAL, "null argument");
     if (!p->aligned) return fail(ESCOIN_ESTATE, "export_aligned before weight_align / set_csr");
+    if (p->is_f64) return fail(ESCOIN_ESTATE, "export_aligned: the aligned form is defined for float plans (a double plan has no generated code to persist; hand its CSR over with escoin_plan_get_csr_f64 / set_csr_f64)");
     const Geometry &g = p->g;
     std::vector<char> jit;
     const int rc = tiled_export(p, &jit);
@@ -611,7 +729,7 @@ int escoin_plan_import_aligned(escoin_plan *p, const void *buf, size_t bytes, vo
     uint64_t sum = 0;
     for (int n : ng) sum += (uint64_t)std::max(0, n);
     if (sum != h.nnz) return fail(ESCOIN_EINVAL, "import_aligned: nnz_per_group does not match the blob's nnz");
-    const int rc = set_csr_host(p, rp.data(), ci.data(), va.data(), ng.data());
+    const int rc = set_csr_host<float>(p, rp.data(), ci.data(), va.data(), ng.data());
     if (rc != ESCOIN_OK) return rc;
     p->aligned = false;
     // the code section only counts for the geometry it was generated for (the LDS offsets in the code
@@ -643,16 +761,19 @@ long escoin_plan_stat(const escoin_plan *p, const char *key) {
   if (!strcmp(key, "streamk_gave_up")) {
     // dense kernel, stream-K launches: 1 if a workgroup's bounded wait for another one's partial sums ran out in
     // the last launch (its results are then wrong); synchronises with the device.  0 for plans that never split K.
-    if (!p->d_sk_ws || p->sk_flag_words < 1) return 0;
+    if (!p->d_sk_ws || p->sk_flag_words < 1 || !p->sk_used) return 0;
     if (p->h_sk_fail && *(volatile unsigned *)p->h_sk_fail != 0u) return 1;      // (sticky: any launch since WeightAlign)
     unsigned v = 0;
     if (hipMemcpy(&v, static_cast<const unsigned *>(p->d_sk_ws) + (p->sk_flag_words - 1), 4, hipMemcpyDeviceToHost) != hipSuccess)
       return fail(ESCOIN_EHIP, "streamk_gave_up: device read failed");
     return (long)v;
   }
-  if (!strcmp(key, "streamk")) return p->d_sk_ws ? 1 : 0;
+  if (!strcmp(key, "streamk")) return p->sk_used ? 1 : 0;
+  if (!strcmp(key, "is_f64")) return p->is_f64 ? 1 : 0;
+  if (!strcmp(key, "host_aligned")) return p->host_aligned ? 1 : 0;
   if (!strcmp(key, "kernel_choice")) {
     if (!p->aligned) return fail(ESCOIN_ESTATE, "kernel_choice before weight_align / set_csr");
+    if (p->is_f64) return ESCOIN_KERNEL_GENERIC;
     if (p->use_dense) return ESCOIN_KERNEL_DENSE;
     if (!p->tiled.enabled) return ESCOIN_KERNEL_GENERIC;
     return p->tiled.jit ? ESCOIN_KERNEL_JIT : ESCOIN_KERNEL_TILED;
@@ -669,34 +790,18 @@ long escoin_plan_nnz(const escoin_plan *p, int group) {
   return n;
 }
 
-int escoin_plan_get_csr(const escoin_plan *p, int *rowptr, int *colidx, float *values,
-                        int stretched) {
-  return guarded([&]() -> int {
-    if (!p || !rowptr) return fail(ESCOIN_EINVAL, "null argument");
-    const Geometry &g = p->g;
-    long base = 0;
-    for (int grp = 0; grp < g.d.group; ++grp) {
-      memcpy(rowptr + (size_t)grp * (g.Mg + 1), p->rowptr[grp].data(), sizeof(int) * (g.Mg + 1));
-      const long n_g = (long)p->colidx[grp].size();
-      for (long j = 0; j < n_g; ++j) {
-        int col = p->colidx[grp][j];
-        if (stretched) {  // base_conv_layer.cpp:99-105
-          const int kc = col % g.d.KW, kr = (col / g.d.KW) % g.d.KH, ic = col / (g.d.KW * g.d.KH);
-          col = (ic * (g.d.H + g.d.pad_h) + kr) * (g.d.W + g.d.pad_w) + kc;
-        }
-        if (colidx) colidx[base + j] = col;
-        if (values) values[base + j] = p->values[grp][j];
-      }
-      base += n_g;
-    }
-    return ESCOIN_OK;
-  });
+int escoin_plan_get_csr(const escoin_plan *p, int *rowptr, int *colidx, float *values, int stretched) {
+  return guarded([&]() -> int { return get_csr_t<float>(p, rowptr, colidx, values, stretched); });
+}
+
+int escoin_plan_get_csr_f64(const escoin_plan *p, int *rowptr, int *colidx, double *values, int stretched) {
+  return guarded([&]() -> int { return get_csr_t<double>(p, rowptr, colidx, values, stretched); });
 }
 
 size_t escoin_plan_workspace_bytes(const escoin_plan *p) { return p ? p->device_bytes : 0; }
 
 const char *escoin_plan_kernel_name(const escoin_plan *p) {
-  if (p && p->aligned && p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE &&
+  if (p && p->aligned && !p->is_f64 && p->conv_mode == ESCOIN_CONV_MODE_LOWERED_SPARSE &&
       p->kernel_choice != ESCOIN_KERNEL_DENSE)
     return lowered_kernel_name();
   return p ? p->kernel_name.c_str() : "";
@@ -711,6 +816,7 @@ int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_de
   return guarded([&]() -> int {
     if (!p || !bottom_dev || !top_dev) return fail(ESCOIN_EINVAL, "null argument");
     if (!p->aligned) return fail(ESCOIN_ESTATE, "forward called before weight_align / set_csr");
+    if (p->is_f64) return fail(ESCOIN_ESTATE, "forward: the plan holds double weights (use escoin_forward_f64)");
     if (n_images < 0 || n_images > p->g.d.N)
       return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
     if (n_images == 0) return ESCOIN_OK;
@@ -738,6 +844,23 @@ int escoin_forward(escoin_plan *p, const float *bottom_dev, const float *bias_de
   });
 }
 
+// Forward_gpu for Dtype = double (conv_layer.cu:75 instantiates the layer for both types): the order-preserving
+// generic kernel in fp64, whatever the conv_mode.
+int escoin_forward_f64(escoin_plan *p, const double *bottom_dev, const double *bias_dev, double *top_dev, int n_images,
+                       void *stream) {
+  return guarded([&]() -> int {
+    if (!p || !bottom_dev || !top_dev) return fail(ESCOIN_EINVAL, "null argument");
+    if (!p->aligned) return fail(ESCOIN_ESTATE, "forward called before weight_align / set_csr");
+    if (!p->is_f64) return fail(ESCOIN_ESTATE, "forward_f64: the plan holds float weights (use escoin_forward)");
+    if (n_images < 0 || n_images > p->g.d.N) return fail(ESCOIN_EINVAL, "n_images outside [0, desc.N]");
+    if (n_images == 0) return ESCOIN_OK;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != p->device)
+      return fail(ESCOIN_ESTATE, "forward: the current device is not the device the plan was aligned on");
+    return launch_generic_f64(p, bottom_dev, bias_dev, top_dev, n_images, (hipStream_t)stream);
+  });
+}
+
 int escoin_gpu_sparse_csrmm(int M, int N, int K, int nnz, float alpha, const float *values,
                             const int *rowptr, const int *colidx, const float *B, float beta, float *C,
                             void *stream) {
@@ -745,8 +868,18 @@ int escoin_gpu_sparse_csrmm(int M, int N, int K, int nnz, float alpha, const flo
   if (M == 0 || N == 0) return ESCOIN_OK;
   if (!rowptr || !C || (nnz > 0 && (!values || !colidx || !B))) return fail(ESCOIN_EINVAL, "null argument");
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return fail(ESCOIN_ENODEVICE, "no HIP device (there is no CPU fallback)");
+  if (hipGetDevice(&dev) != hipSuccess) return fail(ESCOIN_ENODEVICE, "no HIP device (this entry point is the GPU one)");
   return csrmm(M, N, K, alpha, values, rowptr, colidx, B, beta, C, (hipStream_t)stream);
+}
+
+int escoin_gpu_sparse_csrmm_f64(int M, int N, int K, int nnz, double alpha, const double *values, const int *rowptr,
+                                const int *colidx, const double *B, double beta, double *C, void *stream) {
+  if (M < 0 || N < 0 || K < 0 || nnz < 0) return fail(ESCOIN_EINVAL, "negative dimension");
+  if (M == 0 || N == 0) return ESCOIN_OK;
+  if (!rowptr || !C || (nnz > 0 && (!values || !colidx || !B))) return fail(ESCOIN_EINVAL, "null argument");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(ESCOIN_ENODEVICE, "no HIP device (this entry point is the GPU one)");
+  return csrmm_f64(M, N, K, alpha, values, rowptr, colidx, B, beta, C, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,21 @@ int fail(int code, const std::string &msg);
     if (e__ != hipSuccess)                                                            \
       return ::escoin::fail(ESCOIN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
   } while (0)
+
+// No exception may cross the C ABI (std::bad_alloc from the host vectors, std::system_error from a thread team):
+// every entry point that allocates runs its body through this.
+template <typename F>
+inline int guarded(F &&body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(ESCOIN_ENOMEM, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(ESCOIN_EINVAL, std::string("internal error: ") + e.what());
+  } catch (...) {
+    return fail(ESCOIN_EINVAL, "internal error");
+  }
+}
 
 // A nonzero's kernel tap packed for the generic kernel: ic << 16 | kr << 8 | kc
 // (ic group-local).
@@ -65,6 +82,13 @@ struct TiledConfig {
   std::string info;          // escoin_plan_tiling_info
 };
 
+// One host thread's buffers of the CPU mode (sconv_cpu.cpp): the shared-halo padded image and the store scratch.
+struct CpuWorkspace {
+  std::vector<char> pad, scratch;
+  const void *src = nullptr;     // the bottom image the padded buffer currently holds ...
+  unsigned long call = 0;        // ... as of this escoin_forward_cpu call
+};
+
 }  // namespace escoin
 
 struct escoin_plan {
@@ -81,7 +105,20 @@ struct escoin_plan {
   // caffe_cpu_sparse_dense2csr produces (math_functions.cpp:92-105)
   std::vector<std::vector<int>> rowptr;   // [group][Mg+1]
   std::vector<std::vector<int>> colidx;   // [group][nnz_g]
-  std::vector<std::vector<float>> values; // [group][nnz_g]
+  std::vector<std::vector<float>> values; // [group][nnz_g]   (Dtype = float plans)
+  // Dtype = double (conv_layer.cpp:102 INSTANTIATE_CLASS): the align call fixes a plan's type; a double plan keeps its
+  // values here, runs the order-preserving generic kernel on the device (no fast path) and the same host kernel
+  std::vector<std::vector<double>> values64;
+  bool is_f64 = false;
+  double *d_vals64 = nullptr;
+  // Caffe::CPU mode (sconv_cpu.cpp): true once a CSR is on the host, whether or not a device was there to upload to;
+  // cpu_off = the nonzeros' offsets into the shared-halo padded image for THIS geometry (dilation folded in), built on
+  // the first escoin_forward_cpu after an align
+  bool host_aligned = false;
+  std::vector<std::vector<int>> cpu_off;
+  bool cpu_off_valid = false;
+  std::vector<escoin::CpuWorkspace> cpu_ws;   // per team thread: padded image + store scratch
+  unsigned long cpu_calls = 0;
 
   // device arrays for the generic kernel
   int *d_rowptr = nullptr;   // [M+1] absolute offsets into d_taps/d_vals
@@ -116,10 +153,12 @@ struct escoin_plan {
   int stream_stores = -1;         // option "stream_stores": pointwise layers write the top blob with non-temporal stores (1), never (0), by size (-1)
 
   // stream-K workspace of the dense kernel (dense_mfma.hip): flag words, then the partial accumulators; grown on
-  // demand at launch (a plan belongs to one host thread and one stream at a time, like a Caffe layer)
+  // allocated at WeightAlign for layers whose launches may split K (dense_build_ktab): a launch never allocates
   mutable void *d_sk_ws = nullptr;
   mutable size_t sk_ws_bytes = 0;
   mutable int sk_flag_words = 0;
+  mutable bool sk_used = false;            // the last dense launch of this plan split K (escoin_plan_stat "streamk")
+  unsigned *d_sk_fail = nullptr;           // device address of h_sk_fail (looked up once, at WeightAlign)
   mutable unsigned *h_sk_fail = nullptr;   // pinned host word the kernel sets when a fix-up wait gave up (sticky until the next WeightAlign)
 
   // LOWERED_SPARSE comparator (sconv_lowered.hip): column buffer, grown on demand
@@ -132,10 +171,18 @@ struct escoin_plan {
 
 namespace escoin {
 
+// escoin_capi.hip: caffe_cpu_sparse_dense2csr over every conv group of a dense blobs_[0] (math_functions.cpp:92-105,
+// base_conv_layer.cpp:55-66) into the plan's host CSR; fixes the plan's Dtype, releases what an earlier align left on
+// the device and leaves the plan host_aligned (and not device-aligned).  T = float | double.
+template <typename T> void csr_from_dense(escoin_plan *p, const T *w);
+
 // sconv_generic.hip
 int launch_generic(const escoin_plan *p, const float *bottom, const float *bias, float *top,
                    int n_images, hipStream_t stream);
+int launch_generic_f64(const escoin_plan *p, const double *bottom, const double *bias, double *top,
+                       int n_images, hipStream_t stream);
 const char *generic_kernel_name(bool relu);
+const char *generic_kernel_name_f64(bool relu);
 
 // sconv_tiled.hip
 bool tiled_supported(const Geometry &g);
@@ -156,6 +203,8 @@ int launch_lowered(escoin_plan *p, const float *bottom, const float *bias, float
                    hipStream_t stream);
 int csrmm(int M, int N, int K, float alpha, const float *vals, const int *rowptr, const int *colidx,
           const float *B, float beta, float *C, hipStream_t stream);
+int csrmm_f64(int M, int N, int K, double alpha, const double *vals, const int *rowptr, const int *colidx,
+              const double *B, double beta, double *C, hipStream_t stream);
 const char *lowered_kernel_name();
 
 // dense_mfma.hip

@@ -1,0 +1,348 @@
+// sconv_cpu.cpp -- Caffe::CPU mode of the library: the host entry points of include/escoin.h
+// (escoin_weight_align_cpu, escoin_forward_cpu, escoin_cpu_sconv, escoin_cpu_sparse_dense2csr and their _f64 twins).
+//
+//   ConvolutionLayer<Dtype>::Forward_cpu            conv_layer.cpp:25-63       batch loop, bias after
+//     BaseConvolutionLayer::forward_cpu_sconv       base_conv_layer.cpp:569-661 pad copy, per-group kernel call
+//       caffe_cpu_sconv<Dtype>                      math_functions.cpp:128-176
+//     forward_cpu_bias                              base_conv_layer.cpp:663-669
+//   WeightAlign (CPU branch)                        base_conv_layer.cpp:46-107  dense -> CSR -> stretched indices
+//
+// A product-side implementation written for this library (kernel: sconv_cpu_kernel.cpp); it works on a machine with
+// no HIP device and neither includes nor loads anything under oracle/ (tests/ compare the two from outside).
+//
+// Threads: the reference's g++ build runs the batch loop serially and its ICC build parallelises it over images with
+// per-thread padded buffers (conv_layer.cpp:41-44, base_conv_layer.cpp:72-75,605-608).  Here a team of n_threads
+// std::threads takes (image, slice of output channels) items from a shared counter, every thread with its own padded
+// buffer; when the batch has fewer images than threads the output channels of an image are split instead.
+#include <atomic>
+#include <cstring>
+#include <exception>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "escoin_plan.h"
+#include "sconv_cpu.h"
+
+namespace escoin {
+namespace cpu {
+
+enum Isa { kNone = 0, kAvx2 = 2, kAvx512 = 512 };
+
+static Isa detect_isa() {
+  __builtin_cpu_init();
+  if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq"))
+    return kAvx512;
+  if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return kAvx2;
+  return kNone;
+}
+
+static Isa isa() {
+  static const Isa v = detect_isa();
+  return v;
+}
+
+template <typename T>
+static void run_group(const GroupJob<T> &job) {
+  if (isa() == kAvx512)
+    run_group_avx512<T>(job);
+  else
+    run_group_avx2<T>(job);
+}
+
+// Runs body(tid, item) for item = 0 .. n_items-1 on n_threads threads (the caller is thread 0).  The first exception
+// any thread throws stops the hand-out and is rethrown on the caller after every thread has been joined: nothing
+// crosses the C ABI (the entry points run inside guarded()), nothing calls std::terminate.
+template <class F>
+static void team(int n_threads, int n_items, F &&body) {
+  if (n_threads > n_items) n_threads = n_items;
+  if (n_threads < 1) n_threads = 1;
+  std::atomic<int> next(0);
+  std::atomic<bool> stop(false);
+  std::exception_ptr first;
+  std::mutex first_mu;
+  auto worker = [&](int tid) {
+    try {
+      for (;;) {
+        if (stop.load(std::memory_order_relaxed)) return;
+        const int item = next.fetch_add(1);
+        if (item >= n_items) return;
+        body(tid, item);
+      }
+    } catch (...) {
+      stop.store(true);
+      std::lock_guard<std::mutex> lk(first_mu);
+      if (!first) first = std::current_exception();
+    }
+  };
+  struct Joiner {
+    std::vector<std::thread> t;
+    ~Joiner() {
+      for (auto &th : t)
+        if (th.joinable()) th.join();
+    }
+  } pool;
+  try {
+    pool.t.reserve((size_t)n_threads);
+    for (int i = 1; i < n_threads; ++i) pool.t.emplace_back(worker, i);
+  } catch (...) {   // thread creation failed: the threads that exist finish the items together with the caller
+  }
+  worker(0);
+  for (auto &th : pool.t) th.join();
+  pool.t.clear();
+  if (first) std::rethrow_exception(first);
+}
+
+static int resolve_threads(int n_threads) {
+  if (n_threads > 0) return n_threads;
+  const unsigned hc = std::thread::hardware_concurrency();
+  return hc ? (int)hc : 1;
+}
+
+// base_conv_layer.cpp:71 (+ the pad_w floats the reference forgets when pad_h == 0 < pad_w, see escoin_padded_len)
+static size_t padded_len(const Geometry &g) {
+  const escoin_conv_desc &d = g.d;
+  return (size_t)d.C * (d.H + d.pad_h) * (d.W + d.pad_w) + (size_t)d.pad_h * (d.W + 2 * d.pad_w) +
+         (size_t)(d.pad_h == 0 ? d.pad_w : 0);
+}
+
+template <typename T> static const std::vector<std::vector<T>> &plan_values(const escoin_plan *p);
+template <> const std::vector<std::vector<float>> &plan_values<float>(const escoin_plan *p) { return p->values; }
+template <> const std::vector<std::vector<double>> &plan_values<double>(const escoin_plan *p) { return p->values64; }
+
+static void build_offsets(escoin_plan *p) {
+  const Geometry &g = p->g;
+  const int PH = g.d.H + g.d.pad_h, PW = g.d.W + g.d.pad_w;
+  p->cpu_off.assign(g.d.group, std::vector<int>());
+  for (int grp = 0; grp < g.d.group; ++grp) {
+    const std::vector<int> &ci = p->colidx[grp];
+    std::vector<int> &off = p->cpu_off[grp];
+    off.resize(ci.size());
+    for (size_t j = 0; j < ci.size(); ++j) {
+      // the stretch of base_conv_layer.cpp:96-107 with the dilation folded in (the reference decodes it again per
+      // multiply-add in its dilated branch, math_functions.cpp:142-160)
+      const int col = ci[j];
+      const int kc = col % g.d.KW, kr = (col / g.d.KW) % g.d.KH, ic = col / (g.d.KW * g.d.KH);
+      off[j] = (ic * PH + kr * g.d.dil_h) * PW + kc * g.d.dil_w;
+    }
+  }
+  p->cpu_off_valid = true;
+}
+
+template <typename T>
+static int forward_cpu(escoin_plan *p, const T *bottom, const T *bias, T *top, int n_images, int n_threads) {
+  if (!p || !bottom || !top) return fail(ESCOIN_EINVAL, "null argument");
+  if (!p->host_aligned) return fail(ESCOIN_ESTATE, "forward_cpu called before weight_align / set_csr");
+  if (p->is_f64 != (sizeof(T) == 8))
+    return fail(ESCOIN_ESTATE, p->is_f64 ? "forward_cpu: the plan holds double weights (use the _f64 entry point)"
+                                         : "forward_cpu_f64: the plan holds float weights");
+  if (n_images < 0) return fail(ESCOIN_EINVAL, "n_images must be >= 0");
+  if (n_images == 0) return ESCOIN_OK;
+  if (isa() == kNone) return fail(ESCOIN_ENODEVICE, "the CPU path needs AVX2 + FMA (the reference builds with -mavx2 -mfma too)");
+  if (!p->cpu_off_valid) build_offsets(p);
+  const Geometry &g = p->g;
+  const escoin_conv_desc &d = g.d;
+  const int PH = d.H + d.pad_h, PW = d.W + d.pad_w;
+  const bool padded = d.pad_h != 0 || d.pad_w != 0;          // base_conv_layer.cpp:601
+  const size_t plen = padded_len(g);
+  const size_t bottom_dim = (size_t)d.C * d.H * d.W, top_dim = (size_t)d.M * g.OH * g.OW;
+  const auto &values = plan_values<T>(p);
+  n_threads = resolve_threads(n_threads);
+  const unsigned long call_id = ++p->cpu_calls;   // the same blob pointer in a later call holds other data
+  // fewer images than threads: split every image's output channels too
+  int parts = 1;
+  if (n_images < n_threads) parts = std::min(g.Mg, (n_threads + n_images - 1) / n_images);
+  const int n_items = n_images * parts;
+  const int team_size = std::min(n_threads, n_items);
+  constexpr size_t kSlack = 16;   // one vector behind the image: the kernel loads whole vectors at the image's end
+  // per-thread padded buffer + store scratch, kept in the plan between calls (a plan belongs to one host thread at a
+  // time, like a Caffe layer instance); zeroed when (re)allocated -- base_conv_layer.cpp:78-80 -- and only the interior
+  // is ever rewritten
+  if ((int)p->cpu_ws.size() < team_size) p->cpu_ws.resize((size_t)team_size);
+  const size_t pad_bytes = padded ? (plen + kSlack) * sizeof(T) : 0;
+  const size_t scratch_bytes = scratch_elems(g.OH, PW) * sizeof(T);
+  team(team_size, n_items, [&](int tid, int item) {
+    CpuWorkspace &L = p->cpu_ws[(size_t)tid];
+    if (L.pad.size() != pad_bytes) {
+      L.pad.assign(pad_bytes, 0);
+      L.src = nullptr;
+    }
+    if (L.scratch.size() < scratch_bytes) L.scratch.assign(scratch_bytes, 0);
+    const int n = item / parts, part = item - n * parts;
+    const T *image = bottom + (size_t)n * bottom_dim;
+    const T *in_p = image;
+    if (padded) {
+      T *pad = reinterpret_cast<T *>(L.pad.data());
+      if (L.src != (const void *)image || L.call != call_id) {     // (a thread pads an image once for all its channel slices)
+        for (int c = 0; c < d.C; ++c)                             // base_conv_layer.cpp:615-620
+          for (int r = 0; r < d.H; ++r)
+            memcpy(pad + ((size_t)c * PH + r + d.pad_h) * PW + d.pad_w, image + ((size_t)c * d.H + r) * d.W,
+                   sizeof(T) * (size_t)d.W);
+        L.src = image;
+        L.call = call_id;
+      }
+      in_p = pad;
+    }
+    const int m0 = (int)((long)g.Mg * part / parts), m1 = (int)((long)g.Mg * (part + 1) / parts);
+    for (int grp = 0; grp < d.group; ++grp) {                     // base_conv_layer.cpp:626-658
+      GroupJob<T> J;
+      J.in = in_p + (size_t)g.Cg * grp * PH * PW;                 // :633
+      J.rowptr = p->rowptr[grp].data();
+      J.off = p->cpu_off[grp].data();
+      J.val = values[grp].data();
+      J.bias = bias ? bias + (size_t)grp * g.Mg : nullptr;
+      J.out = top + (size_t)n * top_dim + (size_t)grp * g.Mg * g.OH * g.OW;
+      J.m_begin = m0;
+      J.m_end = m1;
+      J.OH = g.OH; J.OW = g.OW; J.PW = PW;
+      J.stride_h = d.stride_h; J.stride_w = d.stride_w;
+      J.relu = d.fuse_relu;
+      J.exact_reads = padded ? 0 : 1;                             // an unpadded layer reads the caller's blob itself
+      J.scratch = reinterpret_cast<T *>(L.scratch.data());
+      run_group<T>(J);
+    }
+  });
+  return ESCOIN_OK;
+}
+
+// caffe_cpu_sconv<Dtype>, math_functions.cpp:128-176, on the caller's buffers (exactly the reference's lengths).
+template <typename T>
+static int cpu_sconv(const T *input_padded, int in_channels, int height, int width, int pad_h, int pad_w, int stride_h,
+                     int stride_w, int dilation_h, int dilation_w, const int *rowptr, const int *colidx, const T *values,
+                     int kernel_h, int kernel_w, T *output, int out_channels, int input_padded_len, int n_threads) {
+  if (!input_padded || !rowptr || !output || in_channels < 1 || height < 1 || width < 1 || pad_h < 0 || pad_w < 0 ||
+      stride_h < 1 || stride_w < 1 || dilation_h < 1 || dilation_w < 1 || kernel_h < 1 || kernel_w < 1 || out_channels < 1)
+    return fail(ESCOIN_EINVAL, "escoin_cpu_sconv: bad argument");
+  if (isa() == kNone) return fail(ESCOIN_ENODEVICE, "the CPU path needs AVX2 + FMA");
+  const int OH = (height + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) / stride_h + 1;   // :136-137
+  const int OW = (width + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) / stride_w + 1;
+  if (OH < 1 || OW < 1) return fail(ESCOIN_EINVAL, "escoin_cpu_sconv: empty output");
+  const int nnz = rowptr[out_channels];
+  if (rowptr[0] != 0 || nnz < 0 || (nnz > 0 && (!colidx || !values)))
+    return fail(ESCOIN_EINVAL, "escoin_cpu_sconv: bad CSR");
+  const int PH = height + pad_h, PW = width + pad_w;
+  // colidx is the stretched index (ic * PH + kr) * PW + kc of base_conv_layer.cpp:96-107; the dilated branch decodes
+  // it (math_functions.cpp:142-160) -- folded into the offsets once here.  The largest element any output reads must
+  // lie inside the caller's buffer (the reference asserts it per multiply-add, :168).
+  std::vector<int> off((size_t)nnz);
+  long max_off = -1;
+  for (int j = 0; j < nnz; ++j) {
+    const int col = colidx[j];
+    if (col < 0) return fail(ESCOIN_EINVAL, "escoin_cpu_sconv: negative column index");
+    int o = col;
+    if (dilation_h != 1 || dilation_w != 1) {
+      const int kc = col % PW, kr = (col / PW) % PH, ic = col / (PW * PH);
+      o = (ic * PH + kr * dilation_h) * PW + kc * dilation_w;
+    }
+    off[(size_t)j] = o;
+    if (o > max_off) max_off = o;
+  }
+  const long last = (long)(OH - 1) * stride_h * PW + (long)(OW - 1) * stride_w;
+  if (nnz > 0 && input_padded_len > 0 && max_off + last >= (long)input_padded_len)
+    return fail(ESCOIN_EINVAL, "escoin_cpu_sconv: a nonzero reads past input_padded_len");
+  n_threads = std::min(resolve_threads(n_threads), out_channels);
+  std::vector<std::vector<T>> scratch((size_t)n_threads);
+  team(n_threads, n_threads, [&](int /*tid*/, int part) {
+    std::vector<T> &sc = scratch[(size_t)part];
+    sc.assign(scratch_elems(OH, PW), T(0));
+    GroupJob<T> J;
+    J.in = input_padded; J.rowptr = rowptr; J.off = off.data(); J.val = values; J.bias = nullptr; J.out = output;
+    J.m_begin = (int)((long)out_channels * part / n_threads);
+    J.m_end = (int)((long)out_channels * (part + 1) / n_threads);
+    J.OH = OH; J.OW = OW; J.PW = PW; J.stride_h = stride_h; J.stride_w = stride_w; J.relu = 0; J.exact_reads = 1;
+    J.scratch = sc.data();
+    run_group<T>(J);
+  });
+  return ESCOIN_OK;
+}
+
+// caffe_cpu_sparse_dense2csr<Dtype>, the hand loop of math_functions.cpp:92-105 (0-based, ascending columns).
+template <typename T>
+static int cpu_dense2csr(int M, int N, const T *A, T *A_nonzero_buf, int *A_nonzero_idx_buf, int *A_idx_pointer_buf) {
+  if (M < 1 || N < 1 || !A || !A_nonzero_buf || !A_nonzero_idx_buf || !A_idx_pointer_buf)
+    return fail(ESCOIN_EINVAL, "escoin_cpu_sparse_dense2csr: bad argument");
+  int nnz = 0;
+  A_idx_pointer_buf[0] = 0;
+  for (int i = 0; i < M; ++i) {
+    const T *row = A + (size_t)i * N;
+    for (int j = 0; j < N; ++j)
+      if (row[j] != 0) {
+        A_nonzero_buf[nnz] = row[j];
+        A_nonzero_idx_buf[nnz] = j;
+        ++nnz;
+      }
+    A_idx_pointer_buf[i + 1] = nnz;
+  }
+  return ESCOIN_OK;
+}
+
+template <typename T>
+static int weight_align_cpu(escoin_plan *p, const T *dense_w) {
+  if (!p || !dense_w) return fail(ESCOIN_EINVAL, "null argument");
+  csr_from_dense<T>(p, dense_w);     // leaves host_aligned = true, the device side (if any) released
+  return ESCOIN_OK;
+}
+
+}  // namespace cpu
+}  // namespace escoin
+
+using namespace escoin;
+
+extern "C" {
+
+const char *escoin_cpu_kernel_name(void) {
+  switch (cpu::isa()) {
+    case cpu::kAvx512: return "escoin_cpu_sconv_avx512";
+    case cpu::kAvx2: return "escoin_cpu_sconv_avx2";
+    default: return "(no AVX2 + FMA: CPU path unavailable)";
+  }
+}
+
+int escoin_weight_align_cpu(escoin_plan *p, const float *dense_w) {
+  return guarded([&]() -> int { return cpu::weight_align_cpu<float>(p, dense_w); });
+}
+int escoin_weight_align_cpu_f64(escoin_plan *p, const double *dense_w) {
+  return guarded([&]() -> int { return cpu::weight_align_cpu<double>(p, dense_w); });
+}
+
+int escoin_forward_cpu(escoin_plan *p, const float *bottom, const float *bias, float *top, int n_images, int n_threads) {
+  return guarded([&]() -> int { return cpu::forward_cpu<float>(p, bottom, bias, top, n_images, n_threads); });
+}
+int escoin_forward_cpu_f64(escoin_plan *p, const double *bottom, const double *bias, double *top, int n_images,
+                           int n_threads) {
+  return guarded([&]() -> int { return cpu::forward_cpu<double>(p, bottom, bias, top, n_images, n_threads); });
+}
+
+int escoin_cpu_sconv(const float *input_padded, int in_channels, int height, int width, int pad_h, int pad_w,
+                     int stride_h, int stride_w, int dilation_h, int dilation_w, const int *rowptr, const int *colidx,
+                     const float *values, int kernel_h, int kernel_w, const float * /*bias: unused, as in the reference*/,
+                     float *output, int out_channels, int input_padded_len) {
+  return guarded([&]() -> int {
+    return cpu::cpu_sconv<float>(input_padded, in_channels, height, width, pad_h, pad_w, stride_h, stride_w, dilation_h,
+                                 dilation_w, rowptr, colidx, values, kernel_h, kernel_w, output, out_channels,
+                                 input_padded_len, 1);
+  });
+}
+int escoin_cpu_sconv_f64(const double *input_padded, int in_channels, int height, int width, int pad_h, int pad_w,
+                         int stride_h, int stride_w, int dilation_h, int dilation_w, const int *rowptr,
+                         const int *colidx, const double *values, int kernel_h, int kernel_w, const double * /*bias*/,
+                         double *output, int out_channels, int input_padded_len) {
+  return guarded([&]() -> int {
+    return cpu::cpu_sconv<double>(input_padded, in_channels, height, width, pad_h, pad_w, stride_h, stride_w,
+                                  dilation_h, dilation_w, rowptr, colidx, values, kernel_h, kernel_w, output,
+                                  out_channels, input_padded_len, 1);
+  });
+}
+
+int escoin_cpu_sparse_dense2csr(int M, int N, const float *A, float *A_nonzero_buf, int *A_nonzero_idx_buf,
+                                int *A_idx_pointer_buf) {
+  return cpu::cpu_dense2csr<float>(M, N, A, A_nonzero_buf, A_nonzero_idx_buf, A_idx_pointer_buf);
+}
+int escoin_cpu_sparse_dense2csr_f64(int M, int N, const double *A, double *A_nonzero_buf, int *A_nonzero_idx_buf,
+                                    int *A_idx_pointer_buf) {
+  return cpu::cpu_dense2csr<double>(M, N, A, A_nonzero_buf, A_nonzero_idx_buf, A_idx_pointer_buf);
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// sconv_cpu.h -- the host (Caffe::CPU mode) half of the library: internal interface between the
+// dispatcher (sconv_cpu.cpp) and the two ISA flavours of the kernel translation unit
+// (sconv_cpu_kernel.cpp compiled with -mavx2 -mfma and with -mavx512f).  Not part of the C ABI.
+//
+// The path it serves:  ConvolutionLayer<Dtype>::Forward_cpu           conv_layer.cpp:25-63
+//                        -> BaseConvolutionLayer::forward_cpu_sconv    base_conv_layer.cpp:569-661
+//                           -> caffe_cpu_sconv<Dtype>                  math_functions.cpp:128-176
+//                        -> forward_cpu_bias                           base_conv_layer.cpp:663-669
+// Nothing here includes, links or loads anything under oracle/.
+#ifndef ESCOIN_SCONV_CPU_H_
+#define ESCOIN_SCONV_CPU_H_
+
+#include <cstddef>
+
+namespace escoin {
+namespace cpu {
+
+// One conv group of one image on the reference's shared-halo padded layout
+// (C x (H + pad_h) x (W + pad_w) floats + tail, base_conv_layer.cpp:71,596-620).
+template <typename T>
+struct GroupJob {
+  const T *in;          // this group's first channel in the padded image
+  const int *rowptr;    // Mg + 1, offsets into off / val
+  const int *off;       // per nonzero: (ic * PH + kr * dil_h) * PW + kc * dil_w  (dilation folded in)
+  const T *val;         // per nonzero, CSR order (ascending columns: the reference's summation order)
+  const T *bias;        // this group's Mg biases or nullptr; added ONCE after the sum (conv_layer.cpp:55-58)
+  T *out;               // this group's first output plane, Mg x OH x OW
+  int m_begin, m_end;   // output channels of the group this call covers
+  int OH, OW, PW;       // PW = W + pad_w: pitch of a padded row
+  int stride_h, stride_w;
+  int relu;             // ConvolutionReLU: max(x + bias, 0)
+  int exact_reads;      // 1: never read past the last input element an output needs (drop-in callers hand over
+                        // buffers of exactly the reference's length); 0: a vector of slack follows the image
+  T *scratch;           // >= scratch_len<T>(OH, PW, OW) elements, private to the calling thread
+};
+
+size_t scratch_elems(int OH, int PW);
+
+// Runs one job.  Each output is sum = fma(val[j], in[...], sum) over the row's nonzeros in CSR order starting from
+// zero, then + bias, then ReLU -- lane for lane the arithmetic of caffe_cpu_sconv, so results are bit-identical to it
+// (and to oracle/, which tests/ checks; this file does not know the oracle exists).
+template <typename T> void run_group_avx2(const GroupJob<T> &job);
+template <typename T> void run_group_avx512(const GroupJob<T> &job);
+
+}  // namespace cpu
+}  // namespace escoin
+#endif

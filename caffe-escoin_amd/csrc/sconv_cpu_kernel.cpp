@@ -1,0 +1,265 @@
+// sconv_cpu_kernel.cpp -- the host kernel of the CPU mode (see sconv_cpu.h), compiled twice by the Makefile:
+//   -DESC_CPU_ISA=2   -mavx2 -mfma                 -> run_group_avx2<float|double>
+//   -DESC_CPU_ISA=512 -mavx512f -mavx512vl ...     -> run_group_avx512<float|double>
+// sconv_cpu.cpp picks one at run time from what the host CPU reports.
+//
+// What the reference does here: caffe_cpu_sconv (math_functions.cpp:162-174) walks pixel -> output channel -> nonzero
+// with one scalar multiply-add per nonzero and a gathered load; its ICC-only fast path sconv_unit_stride
+// (sconv.hpp:57-589) keeps a register tile of output pixels per output channel and streams the channel's nonzeros
+// over it.  This kernel is built on that second idea, redone for the shared-halo layout as it is:
+//
+//   * stride 1 (any dilation): on the padded layout an output pixel q = oh * PW + ow reads in[off_j + q] for every
+//     nonzero j, so the "virtual" pixels 0 .. (OH-1) * PW + OW - 1 are ONE contiguous axis: a tile is NV vector
+//     registers of consecutive virtual pixels, rows and images of any width fill whole vectors (7x7 and 13x13 layers
+//     do not waste lanes per row), and the pad_w virtual pixels per row that are not outputs are dropped at the store;
+//   * tile outer, output channel inner: the tile's input window (all channels x NV vectors) stays in L1 while every
+//     channel's nonzeros stream over it once;
+//   * per nonzero: one broadcast of the value, one scalar offset, NV fused multiply-adds with a memory operand.
+//   * other strides: one output row at a time, scalar lanes (the reference's fast kernels do not cover them either,
+//     math_functions.cpp:201-462).
+//
+// Summation order per output is the CSR order from zero, fused multiply-add, bias added afterwards once, then ReLU:
+// exactly the reference's, so the results are bit-identical to caffe_cpu_sconv's whatever the tile shape.
+#include <immintrin.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "sconv_cpu.h"
+
+#ifndef ESC_CPU_ISA
+#error "compile with -DESC_CPU_ISA=2 or -DESC_CPU_ISA=512"
+#endif
+
+namespace escoin {
+namespace cpu {
+namespace {
+
+template <typename T> struct Vec;
+
+#if ESC_CPU_ISA == 512
+template <> struct Vec<float> {
+  typedef __m512 V;
+  enum { L = 16 };
+  static V zero() { return _mm512_setzero_ps(); }
+  static V bcast(float x) { return _mm512_set1_ps(x); }
+  static V load(const float *p) { return _mm512_loadu_ps(p); }
+  static V load_n(const float *p, int n) { return _mm512_maskz_loadu_ps((__mmask16)((1u << n) - 1u), p); }
+  static void store(float *p, V v) { _mm512_storeu_ps(p, v); }
+  static V fma(V a, V b, V c) { return _mm512_fmadd_ps(a, b, c); }
+  static V add(V a, V b) { return _mm512_add_ps(a, b); }
+  static V relu(V a) { return _mm512_max_ps(a, _mm512_setzero_ps()); }
+};
+template <> struct Vec<double> {
+  typedef __m512d V;
+  enum { L = 8 };
+  static V zero() { return _mm512_setzero_pd(); }
+  static V bcast(double x) { return _mm512_set1_pd(x); }
+  static V load(const double *p) { return _mm512_loadu_pd(p); }
+  static V load_n(const double *p, int n) { return _mm512_maskz_loadu_pd((__mmask8)((1u << n) - 1u), p); }
+  static void store(double *p, V v) { _mm512_storeu_pd(p, v); }
+  static V fma(V a, V b, V c) { return _mm512_fmadd_pd(a, b, c); }
+  static V add(V a, V b) { return _mm512_add_pd(a, b); }
+  static V relu(V a) { return _mm512_max_pd(a, _mm512_setzero_pd()); }
+};
+constexpr int kMaxVecs = 14;   // 32 vector registers: 14 accumulators + the broadcast leave room to spare
+#else
+static inline __m256i mask8(int n) {
+  const __m256i idx = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+  return _mm256_cmpgt_epi32(_mm256_set1_epi32(n), idx);
+}
+static inline __m256i mask4(int n) {
+  const __m256i idx = _mm256_setr_epi64x(0, 1, 2, 3);
+  return _mm256_cmpgt_epi64(_mm256_set1_epi64x(n), idx);
+}
+template <> struct Vec<float> {
+  typedef __m256 V;
+  enum { L = 8 };
+  static V zero() { return _mm256_setzero_ps(); }
+  static V bcast(float x) { return _mm256_set1_ps(x); }
+  static V load(const float *p) { return _mm256_loadu_ps(p); }
+  static V load_n(const float *p, int n) { return _mm256_maskload_ps(p, mask8(n)); }
+  static void store(float *p, V v) { _mm256_storeu_ps(p, v); }
+  static V fma(V a, V b, V c) { return _mm256_fmadd_ps(a, b, c); }
+  static V add(V a, V b) { return _mm256_add_ps(a, b); }
+  static V relu(V a) { return _mm256_max_ps(a, _mm256_setzero_ps()); }
+};
+template <> struct Vec<double> {
+  typedef __m256d V;
+  enum { L = 4 };
+  static V zero() { return _mm256_setzero_pd(); }
+  static V bcast(double x) { return _mm256_set1_pd(x); }
+  static V load(const double *p) { return _mm256_loadu_pd(p); }
+  static V load_n(const double *p, int n) { return _mm256_maskload_pd(p, mask4(n)); }
+  static void store(double *p, V v) { _mm256_storeu_pd(p, v); }
+  static V fma(V a, V b, V c) { return _mm256_fmadd_pd(a, b, c); }
+  static V add(V a, V b) { return _mm256_add_pd(a, b); }
+  static V relu(V a) { return _mm256_max_pd(a, _mm256_setzero_pd()); }
+};
+constexpr int kMaxVecs = 12;   // 16 vector registers: 12 accumulators, the broadcast, spare
+#endif
+
+struct Seg { int dst, src, len; };   // a run of real outputs inside a tile of virtual pixels
+
+// One tile of NV vectors starting at virtual pixel q0, every output channel of the job.
+//   masked_n: valid lanes of the LAST vector when its load must not run past them (1 .. L-1), 0 = load it whole.
+template <typename T, int NV>
+static void tile_unit_stride(const GroupJob<T> &J, int q0, int masked_n, const Seg *segs, int nseg, bool direct,
+                             int n_valid) {
+  typedef Vec<T> X;
+  typedef typename X::V V;
+  constexpr int L = X::L;
+  const T *base = J.in + q0;
+  const size_t plane = (size_t)J.OH * J.OW;
+  for (int m = J.m_begin; m < J.m_end; ++m) {
+    V acc[NV];
+    for (int t = 0; t < NV; ++t) acc[t] = X::zero();
+    const int jb = J.rowptr[m], je = J.rowptr[m + 1];
+    if (masked_n == 0) {
+      for (int j = jb; j < je; ++j) {
+        const V v = X::bcast(J.val[j]);
+        const T *p = base + J.off[j];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) acc[t] = X::fma(v, X::load(p + t * L), acc[t]);
+      }
+    } else {
+      for (int j = jb; j < je; ++j) {
+        const V v = X::bcast(J.val[j]);
+        const T *p = base + J.off[j];
+#pragma unroll
+        for (int t = 0; t < NV - 1; ++t) acc[t] = X::fma(v, X::load(p + t * L), acc[t]);
+        acc[NV - 1] = X::fma(v, X::load_n(p + (NV - 1) * L, masked_n), acc[NV - 1]);
+      }
+    }
+    if (J.bias) {
+      const V b = X::bcast(J.bias[m]);
+      for (int t = 0; t < NV; ++t) acc[t] = X::add(acc[t], b);
+    }
+    if (J.relu)
+      for (int t = 0; t < NV; ++t) acc[t] = X::relu(acc[t]);
+    T *outp = J.out + (size_t)m * plane;
+    if (direct && n_valid == NV * L) {
+      for (int t = 0; t < NV; ++t) X::store(outp + q0 + t * L, acc[t]);
+    } else {
+      for (int t = 0; t < NV; ++t) X::store(J.scratch + t * L, acc[t]);
+      for (int s = 0; s < nseg; ++s) memcpy(outp + segs[s].dst, J.scratch + segs[s].src, sizeof(T) * (size_t)segs[s].len);
+    }
+  }
+}
+
+template <typename T, int NV>
+struct TileTable {
+  static void fill(void (**tab)(const GroupJob<T> &, int, int, const Seg *, int, bool, int)) {
+    tab[NV] = &tile_unit_stride<T, NV>;
+    TileTable<T, NV - 1>::fill(tab);
+  }
+};
+template <typename T>
+struct TileTable<T, 0> {
+  static void fill(void (**)(const GroupJob<T> &, int, int, const Seg *, int, bool, int)) {}
+};
+
+template <typename T>
+static void run_unit_stride(const GroupJob<T> &J) {
+  constexpr int L = Vec<T>::L;
+  typedef void (*TileFn)(const GroupJob<T> &, int, int, const Seg *, int, bool, int);
+  struct Table {
+    TileFn fn[kMaxVecs + 1];
+    Table() { fn[0] = nullptr; TileTable<T, kMaxVecs>::fill(fn); }
+  };
+  static const Table table;   // (a function-local static: initialised once, thread-safe)
+  const int Q = (J.OH - 1) * J.PW + J.OW;               // virtual pixels
+  const int nvec = (Q + L - 1) / L;
+  const int ntiles = (nvec + kMaxVecs - 1) / kMaxVecs;
+  const int per_tile = (nvec + ntiles - 1) / ntiles;     // evenly sized tiles (14 x 14: 7 + 7 vectors, not 12 + 2)
+  const bool direct = J.PW == J.OW;                      // no dropped columns: virtual pixel == output index
+  // the runs of real outputs of one tile (at most rows-in-a-tile + 1 of them)
+  Seg segs[kMaxVecs * 16 + 2];
+  for (int t0 = 0; t0 < nvec; t0 += per_tile) {
+    const int nv = std::min(per_tile, nvec - t0);
+    const int q0 = t0 * L, q1 = std::min(Q, q0 + nv * L);
+    int nseg = 0;
+    for (int q = q0; q < q1;) {
+      const int oh = q / J.PW, ow = q - oh * J.PW;
+      const int run = std::min(q1 - q, J.PW - ow);
+      const int keep = std::min(run, J.OW - ow);
+      if (keep > 0) {
+        segs[nseg].dst = oh * J.OW + ow;
+        segs[nseg].src = q - q0;
+        segs[nseg].len = keep;
+        ++nseg;
+      }
+      q += run;
+    }
+    const int tail = q1 - (q0 + (nv - 1) * L);           // valid lanes of the last vector, 1 .. L
+    const int masked_n = (J.exact_reads && tail < L) ? tail : 0;
+    table.fn[nv](J, q0, masked_n, segs, nseg, direct, q1 - q0);
+  }
+}
+
+// Any stride: one output row at a time, kB scalar accumulators along the row so that a nonzero's value and offset
+// are loaded once per kB outputs.
+template <typename T>
+static void run_any_stride(const GroupJob<T> &J) {
+  constexpr int kB = 8;
+  const size_t plane = (size_t)J.OH * J.OW;
+  for (int m = J.m_begin; m < J.m_end; ++m) {
+    const int jb = J.rowptr[m], je = J.rowptr[m + 1];
+    const T b = J.bias ? J.bias[m] : T(0);
+    T *outp = J.out + (size_t)m * plane;
+    for (int oh = 0; oh < J.OH; ++oh) {
+      const T *row = J.in + (size_t)oh * J.stride_h * J.PW;
+      for (int ow0 = 0; ow0 < J.OW; ow0 += kB) {
+        const int nb = std::min(kB, J.OW - ow0);
+        T acc[kB];
+        for (int e = 0; e < kB; ++e) acc[e] = T(0);
+        const T *p0 = row + (size_t)ow0 * J.stride_w;
+        if (nb == kB) {
+          for (int j = jb; j < je; ++j) {
+            const T v = J.val[j];
+            const T *p = p0 + J.off[j];
+            for (int e = 0; e < kB; ++e) acc[e] = std::fma(v, p[(size_t)e * J.stride_w], acc[e]);
+          }
+        } else {
+          for (int j = jb; j < je; ++j) {
+            const T v = J.val[j];
+            const T *p = p0 + J.off[j];
+            for (int e = 0; e < nb; ++e) acc[e] = std::fma(v, p[(size_t)e * J.stride_w], acc[e]);
+          }
+        }
+        for (int e = 0; e < nb; ++e) {
+          T r = acc[e];
+          if (J.bias) r += b;
+          if (J.relu) r = r > T(0) ? r : T(0);
+          outp[(size_t)oh * J.OW + ow0 + e] = r;
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static void run_group(const GroupJob<T> &J) {
+  if (J.m_end <= J.m_begin || J.OH < 1 || J.OW < 1) return;
+  if (J.stride_h == 1 && J.stride_w == 1)
+    run_unit_stride<T>(J);
+  else
+    run_any_stride<T>(J);
+}
+
+}  // namespace
+
+#if ESC_CPU_ISA == 512
+template <typename T> void run_group_avx512(const GroupJob<T> &job) { run_group<T>(job); }
+template void run_group_avx512<float>(const GroupJob<float> &);
+template void run_group_avx512<double>(const GroupJob<double> &);
+#else
+size_t scratch_elems(int /*OH*/, int /*PW*/) { return 16 * 16; }   // one tile of the widest flavour (14 x 16 floats), rounded up
+template <typename T> void run_group_avx2(const GroupJob<T> &job) { run_group<T>(job); }
+template void run_group_avx2<float>(const GroupJob<float> &);
+template void run_group_avx2<double>(const GroupJob<double> &);
+#endif
+
+}  // namespace cpu
+}  // namespace escoin

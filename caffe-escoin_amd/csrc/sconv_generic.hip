@@ -25,22 +25,27 @@ namespace escoin {
 
 constexpr int kWavesPerBlock = 4;
 
+// (T = float | double: the reference instantiates the layer for both, conv_layer.cu:75; fp64 vector FMA is native here)
+template <typename T>
 struct GenericArgs {
-  const float *__restrict__ in;
-  float *__restrict__ out;
+  const T *__restrict__ in;
+  T *__restrict__ out;
   const int *__restrict__ rowptr;
   const int *__restrict__ taps;
-  const float *__restrict__ vals;
-  const float *__restrict__ bias;
+  const T *__restrict__ vals;
+  const T *__restrict__ bias;
   int C, H, W, M, OH, OW;
   int pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
   int Cg, Mg;
   unsigned long long group_mask;   // conv groups this launch covers (the others: MFMA kernel)
 };
 
-template <bool RELU>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
-escoin_sconv_generic_kernel(GenericArgs a) {
+template <typename T> __device__ inline T fma_t(T a, T b, T c);
+template <> __device__ inline float fma_t<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ inline double fma_t<double>(double a, double b, double c) { return fma(a, b, c); }
+
+template <typename T, bool RELU>
+__device__ inline void sconv_generic_body(const GenericArgs<T> &a) {
   const int lane = threadIdx.x;
   const int oc = __builtin_amdgcn_readfirstlane(blockIdx.y * kWavesPerBlock + threadIdx.y);
   if (oc >= a.M) return;
@@ -54,38 +59,51 @@ escoin_sconv_generic_kernel(GenericArgs a) {
   const int iw0 = ow * a.stride_w - a.pad_w;
   const int grp = oc / a.Mg;
   if (a.group_mask != ~0ull && !((a.group_mask >> grp) & 1ull)) return;   // wave-uniform
-  const float *__restrict__ img = a.in + ((size_t)n * a.C + (size_t)grp * a.Cg) * a.H * a.W;
+  const T *__restrict__ img = a.in + ((size_t)n * a.C + (size_t)grp * a.Cg) * a.H * a.W;
   const int jb = a.rowptr[oc], je = a.rowptr[oc + 1];
-  float sum = 0.f;
+  T sum = 0;
   for (int j = jb; j < je; ++j) {
     const int tap = a.taps[j];
-    const float v = a.vals[j];
+    const T v = a.vals[j];
     const int ic = tap >> 16, kr = (tap >> 8) & 0xff, kc = tap & 0xff;
     const int ih = ih0 + kr * a.dil_h;
     const int iw = iw0 + kc * a.dil_w;
-    float x = 0.f;
+    T x = 0;
     if (live && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
       x = img[((size_t)ic * a.H + ih) * a.W + iw];
-    sum = fmaf(v, x, sum);
+    sum = fma_t<T>(v, x, sum);
   }
   if (a.bias) sum += a.bias[oc];
-  if (RELU) sum = fmaxf(sum, 0.f);
+  if (RELU) sum = sum > T(0) ? sum : T(0);
   if (live) a.out[((size_t)n * a.M + oc) * npix + p] = sum;
 }
+
+// (two kernel names, not one template over T: the float kernel keeps the symbol rocprofv3 has reported since round 1)
+template <bool RELU>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+escoin_sconv_generic_kernel(GenericArgs<float> a) { sconv_generic_body<float, RELU>(a); }
+
+template <bool RELU>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+escoin_sconv_generic_f64_kernel(GenericArgs<double> a) { sconv_generic_body<double, RELU>(a); }
 
 const char *generic_kernel_name(bool relu) {
   return relu ? "escoin_sconv_generic_kernel<true>" : "escoin_sconv_generic_kernel<false>";
 }
+const char *generic_kernel_name_f64(bool relu) {
+  return relu ? "escoin_sconv_generic_f64_kernel<true>" : "escoin_sconv_generic_f64_kernel<false>";
+}
 
-int launch_generic(const escoin_plan *p, const float *bottom, const float *bias, float *top,
-                   int n_images, hipStream_t stream) {
+template <typename T>
+static int launch_generic_t(const escoin_plan *p, const T *vals, const T *bottom, const T *bias, T *top, int n_images,
+                            hipStream_t stream) {
   const Geometry &g = p->g;
-  GenericArgs a;
+  GenericArgs<T> a;
   a.in = bottom;
   a.out = top;
   a.rowptr = p->d_rowptr;
   a.taps = p->d_taps;
-  a.vals = p->d_vals;
+  a.vals = vals;
   a.bias = bias;
   a.C = g.d.C; a.H = g.d.H; a.W = g.d.W; a.M = g.d.M; a.OH = g.OH; a.OW = g.OW;
   a.pad_h = g.d.pad_h; a.pad_w = g.d.pad_w; a.stride_h = g.d.stride_h; a.stride_w = g.d.stride_w;
@@ -96,25 +114,42 @@ int launch_generic(const escoin_plan *p, const float *bottom, const float *bias,
   dim3 grid((npix + 63) / 64, (g.d.M + kWavesPerBlock - 1) / kWavesPerBlock, n_images);
   if (grid.y > 65535u || grid.z > 65535u)
     return fail(ESCOIN_EINVAL, "generic kernel: grid dimension exceeds 65535");
-  if (g.d.fuse_relu)
-    hipLaunchKernelGGL(escoin_sconv_generic_kernel<true>, grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL(escoin_sconv_generic_kernel<false>, grid, block, 0, stream, a);
+  if constexpr (sizeof(T) == 8) {
+    if (g.d.fuse_relu)
+      hipLaunchKernelGGL(escoin_sconv_generic_f64_kernel<true>, grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL(escoin_sconv_generic_f64_kernel<false>, grid, block, 0, stream, a);
+  } else {
+    if (g.d.fuse_relu)
+      hipLaunchKernelGGL(escoin_sconv_generic_kernel<true>, grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL(escoin_sconv_generic_kernel<false>, grid, block, 0, stream, a);
+  }
   ESCOIN_HIP_TRY(hipGetLastError());
   return ESCOIN_OK;
+}
+
+int launch_generic(const escoin_plan *p, const float *bottom, const float *bias, float *top, int n_images,
+                   hipStream_t stream) {
+  return launch_generic_t<float>(p, p->d_vals, bottom, bias, top, n_images, stream);
+}
+int launch_generic_f64(const escoin_plan *p, const double *bottom, const double *bias, double *top, int n_images,
+                       hipStream_t stream) {
+  return launch_generic_t<double>(p, p->d_vals64, bottom, bias, top, n_images, stream);
 }
 
 // ------------------------------------------------------------------------------------
 // math_functions-level drop-ins
 // ------------------------------------------------------------------------------------
 
+template <typename T>
 struct PaddedArgs {
-  const float *__restrict__ in;
-  float *__restrict__ out;
+  const T *__restrict__ in;
+  T *__restrict__ out;
   const int *__restrict__ rowptr;
   const int *__restrict__ colidx;
-  const float *__restrict__ vals;
-  const float *__restrict__ bias;
+  const T *__restrict__ vals;
+  const T *__restrict__ bias;
   int H, W, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w;
   int OH, OW, num_oc;
   long in_stride;   // floats between consecutive images of the padded input
@@ -123,9 +158,9 @@ struct PaddedArgs {
 
 // One lane = one output pixel of (image n, channel oc); same arithmetic as
 // caffe_cpu_sconv incl. the dilated branch's index decode (math_functions.cpp:142-160).
-template <bool RELU, bool DILATED>
+template <typename T, bool RELU, bool DILATED>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
-escoin_sconv_padded_kernel(PaddedArgs a) {
+escoin_sconv_padded_kernel(PaddedArgs<T> a) {
   const int lane = threadIdx.x;
   const int oc = __builtin_amdgcn_readfirstlane(blockIdx.y * kWavesPerBlock + threadIdx.y);
   if (oc >= a.num_oc) return;
@@ -136,13 +171,13 @@ escoin_sconv_padded_kernel(PaddedArgs a) {
   const int oh = live ? p / a.OW : 0;
   const int ow = live ? p - oh * a.OW : 0;
   const int PW = a.W + a.pad_w, PH = a.H + a.pad_h;
-  const float *__restrict__ img = a.in + (size_t)n * a.in_stride;
-  const float *__restrict__ base = img + (size_t)oh * a.stride_h * PW + ow * a.stride_w;
-  float sum = RELU ? a.bias[oc] : 0.f;  // math_functions.cu:215,421 vs :282
+  const T *__restrict__ img = a.in + (size_t)n * a.in_stride;
+  const T *__restrict__ base = img + (size_t)oh * a.stride_h * PW + ow * a.stride_w;
+  T sum = RELU ? a.bias[oc] : T(0);  // math_functions.cu:215,421 vs :282
   for (int j = a.rowptr[oc]; j < a.rowptr[oc + 1]; ++j) {
     const int col = a.colidx[j];
-    const float v = a.vals[j];
-    float x;
+    const T v = a.vals[j];
+    T x;
     if (DILATED) {
       const int kc = col % PW, kr = (col / PW) % PH, ic = col / (PW * PH);
       x = img[((size_t)ic * PH + kr * a.dil_h + oh * a.stride_h) * PW + kc * a.dil_w +
@@ -150,9 +185,9 @@ escoin_sconv_padded_kernel(PaddedArgs a) {
     } else {
       x = base[col];
     }
-    sum = fmaf(v, x, sum);
+    sum = fma_t<T>(v, x, sum);
   }
-  if (RELU) sum = fmaxf(sum, 0.f);
+  if (RELU) sum = sum > T(0) ? sum : T(0);
   if (live) a.out[(size_t)n * a.out_stride + (size_t)oc * npix + p] = sum;
 }
 
@@ -169,7 +204,8 @@ __global__ void escoin_stretch_kernel(const int *__restrict__ rowptr, int *__res
   }
 }
 
-__global__ void escoin_copy_input_kernel(float *__restrict__ dst, const float *__restrict__ src,
+template <typename T>
+__global__ void escoin_copy_input_kernel(T *__restrict__ dst, const T *__restrict__ src,
                                          int C, int H, int W, int pad_h, int pad_w) {
   const long total = (long)C * H * W;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -182,27 +218,29 @@ __global__ void escoin_copy_input_kernel(float *__restrict__ dst, const float *_
   }
 }
 
-__global__ void escoin_row_nnz_kernel(const float *__restrict__ A, int M, int N,
+template <typename T>
+__global__ void escoin_row_nnz_kernel(const T *__restrict__ A, int M, int N,
                                       int *__restrict__ nnz_per_row) {
   const int row = blockIdx.x;
   if (row >= M) return;
   int cnt = 0;
-  for (int j = threadIdx.x; j < N; j += 64) cnt += (A[(size_t)row * N + j] != 0.f) ? 1 : 0;
+  for (int j = threadIdx.x; j < N; j += 64) cnt += (A[(size_t)row * N + j] != T(0)) ? 1 : 0;
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
   if (threadIdx.x == 0) nnz_per_row[row] = cnt;
 }
 
 // One wave per row; ballot-compaction keeps ascending column order.
-__global__ void escoin_row_fill_kernel(const float *__restrict__ A, int M, int N,
-                                       const int *__restrict__ rowptr, float *__restrict__ vals,
+template <typename T>
+__global__ void escoin_row_fill_kernel(const T *__restrict__ A, int M, int N,
+                                       const int *__restrict__ rowptr, T *__restrict__ vals,
                                        int *__restrict__ cols) {
   const int row = blockIdx.x;
   if (row >= M) return;
   int base = rowptr[row];
   for (int j0 = 0; j0 < N; j0 += 64) {
     const int j = j0 + threadIdx.x;
-    const float v = j < N ? A[(size_t)row * N + j] : 0.f;
-    const bool nz = v != 0.f;
+    const T v = j < N ? A[(size_t)row * N + j] : T(0);
+    const bool nz = v != T(0);
     const unsigned long long m = __ballot(nz);
     const int before = __popcll(m & ((1ull << threadIdx.x) - 1ull));
     if (nz) {
@@ -215,19 +253,18 @@ __global__ void escoin_row_fill_kernel(const float *__restrict__ A, int M, int N
 
 }  // namespace escoin
 
-using namespace escoin;
+namespace escoin {
 
-extern "C" int escoin_gpu_sconv(int fuse_relu, int num, const float *input, int ifmap_size,
-                                const int *rowptr, const int *colidx, const float *values,
-                                const float *bias, int height, int width, int pad_h, int pad_w,
-                                int stride_h, int stride_w, int dilation_h, int dilation_w,
-                                int kernel_h, int kernel_w, float *output, int num_oc,
-                                int num_groups, void *stream) {
+template <typename T>
+static int gpu_sconv_t(int fuse_relu, int num, const T *input, int ifmap_size, const int *rowptr, const int *colidx,
+                       const T *values, const T *bias, int height, int width, int pad_h, int pad_w, int stride_h,
+                       int stride_w, int dilation_h, int dilation_w, int kernel_h, int kernel_w, T *output, int num_oc,
+                       int num_groups, void *stream) {
   if (!input || !rowptr || !colidx || !values || !output || num < 1 || num_oc < 1 ||
       num_groups < 1 || stride_h < 1 || stride_w < 1 || dilation_h < 1 || dilation_w < 1)
     return fail(ESCOIN_EINVAL, "escoin_gpu_sconv: bad argument");
   if (fuse_relu && !bias) return fail(ESCOIN_EINVAL, "escoin_gpu_sconv: FUSE_RELU needs bias");
-  PaddedArgs a;
+  PaddedArgs<T> a;
   a.in = input; a.out = output; a.rowptr = rowptr; a.colidx = colidx; a.vals = values;
   a.bias = bias;
   a.H = height; a.W = width; a.pad_h = pad_h; a.pad_w = pad_w;
@@ -243,14 +280,82 @@ extern "C" int escoin_gpu_sconv(int fuse_relu, int num, const float *input, int 
   hipStream_t s = (hipStream_t)stream;
   const bool dil = dilation_h != 1 || dilation_w != 1;
   if (fuse_relu) {
-    if (dil) hipLaunchKernelGGL((escoin_sconv_padded_kernel<true, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((escoin_sconv_padded_kernel<true, false>), grid, block, 0, s, a);
+    if (dil) hipLaunchKernelGGL((escoin_sconv_padded_kernel<T, true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((escoin_sconv_padded_kernel<T, true, false>), grid, block, 0, s, a);
   } else {
-    if (dil) hipLaunchKernelGGL((escoin_sconv_padded_kernel<false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((escoin_sconv_padded_kernel<false, false>), grid, block, 0, s, a);
+    if (dil) hipLaunchKernelGGL((escoin_sconv_padded_kernel<T, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((escoin_sconv_padded_kernel<T, false, false>), grid, block, 0, s, a);
   }
   ESCOIN_HIP_TRY(hipGetLastError());
   return ESCOIN_OK;
+}
+
+template <typename T>
+static int copy_input_t(T *dst, const T *src, int num_channels, int height, int width, int pad_h, int pad_w,
+                        void *stream) {
+  if (!dst || !src || num_channels < 1 || height < 1 || width < 1)
+    return fail(ESCOIN_EINVAL, "escoin_copy_input_data: bad argument");
+  const long total = (long)num_channels * height * width;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(escoin_copy_input_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     dst, src, num_channels, height, width, pad_h, pad_w);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  return ESCOIN_OK;
+}
+
+template <typename T>
+static int dense2csr_t(int M, int N, const T *A, int *nnz_per_row, T *A_nonzero_buf, int *A_idx_pointer_buf,
+                       int *A_nonzero_idx_buf, int *nnz_total, void *stream) {
+  if (M < 1 || N < 1 || !A || !nnz_per_row || !A_nonzero_buf || !A_idx_pointer_buf ||
+      !A_nonzero_idx_buf || !nnz_total)
+    return fail(ESCOIN_EINVAL, "escoin_gpu_sparse_dense2csr: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(escoin_row_nnz_kernel<T>, dim3(M), dim3(64), 0, s, A, M, N, nnz_per_row);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  std::vector<int> cnt(M), ptr(M + 1);
+  ESCOIN_HIP_TRY(hipMemcpyAsync(cnt.data(), nnz_per_row, sizeof(int) * M, hipMemcpyDeviceToHost, s));
+  ESCOIN_HIP_TRY(hipStreamSynchronize(s));
+  ptr[0] = 0;
+  for (int i = 0; i < M; ++i) ptr[i + 1] = ptr[i] + cnt[i];
+  ESCOIN_HIP_TRY(hipMemcpyAsync(A_idx_pointer_buf, ptr.data(), sizeof(int) * (M + 1),
+                                hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(escoin_row_fill_kernel<T>, dim3(M), dim3(64), 0, s, A, M, N,
+                     (const int *)A_idx_pointer_buf, A_nonzero_buf, A_nonzero_idx_buf);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  ESCOIN_HIP_TRY(hipStreamSynchronize(s));  // ptr (host) must outlive the async copy
+  *nnz_total = ptr[M];
+  return ESCOIN_OK;
+}
+
+}  // namespace escoin
+
+using namespace escoin;
+
+extern "C" int escoin_gpu_sconv(int fuse_relu, int num, const float *input, int ifmap_size,
+                                const int *rowptr, const int *colidx, const float *values,
+                                const float *bias, int height, int width, int pad_h, int pad_w,
+                                int stride_h, int stride_w, int dilation_h, int dilation_w,
+                                int kernel_h, int kernel_w, float *output, int num_oc,
+                                int num_groups, void *stream) {
+  return guarded([&]() -> int {
+    return gpu_sconv_t<float>(fuse_relu, num, input, ifmap_size, rowptr, colidx, values, bias, height, width, pad_h,
+                              pad_w, stride_h, stride_w, dilation_h, dilation_w, kernel_h, kernel_w, output, num_oc,
+                              num_groups, stream);
+  });
+}
+
+extern "C" int escoin_gpu_sconv_f64(int fuse_relu, int num, const double *input, int ifmap_size,
+                                    const int *rowptr, const int *colidx, const double *values,
+                                    const double *bias, int height, int width, int pad_h, int pad_w,
+                                    int stride_h, int stride_w, int dilation_h, int dilation_w,
+                                    int kernel_h, int kernel_w, double *output, int num_oc,
+                                    int num_groups, void *stream) {
+  return guarded([&]() -> int {
+    return gpu_sconv_t<double>(fuse_relu, num, input, ifmap_size, rowptr, colidx, values, bias, height, width, pad_h,
+                               pad_w, stride_h, stride_w, dilation_h, dilation_w, kernel_h, kernel_w, output, num_oc,
+                               num_groups, stream);
+  });
 }
 
 extern "C" int escoin_gpu_stretch(const int *rowptr, int *colidx, int M, int height, int width,
@@ -267,38 +372,28 @@ extern "C" int escoin_gpu_stretch(const int *rowptr, int *colidx, int M, int hei
 
 extern "C" int escoin_copy_input_data(float *dst, const float *src, int num_channels, int height,
                                       int width, int pad_h, int pad_w, void *stream) {
-  if (!dst || !src || num_channels < 1 || height < 1 || width < 1)
-    return fail(ESCOIN_EINVAL, "escoin_copy_input_data: bad argument");
-  const long total = (long)num_channels * height * width;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(escoin_copy_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                     dst, src, num_channels, height, width, pad_h, pad_w);
-  ESCOIN_HIP_TRY(hipGetLastError());
-  return ESCOIN_OK;
+  return copy_input_t<float>(dst, src, num_channels, height, width, pad_h, pad_w, stream);
+}
+
+extern "C" int escoin_copy_input_data_f64(double *dst, const double *src, int num_channels, int height,
+                                          int width, int pad_h, int pad_w, void *stream) {
+  return copy_input_t<double>(dst, src, num_channels, height, width, pad_h, pad_w, stream);
 }
 
 extern "C" int escoin_gpu_sparse_dense2csr(int M, int N, const float *A, int *nnz_per_row,
                                            float *A_nonzero_buf, int *A_idx_pointer_buf,
                                            int *A_nonzero_idx_buf, int *nnz_total,
                                            void *stream) {
-  if (M < 1 || N < 1 || !A || !nnz_per_row || !A_nonzero_buf || !A_idx_pointer_buf ||
-      !A_nonzero_idx_buf || !nnz_total)
-    return fail(ESCOIN_EINVAL, "escoin_gpu_sparse_dense2csr: bad argument");
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(escoin_row_nnz_kernel, dim3(M), dim3(64), 0, s, A, M, N, nnz_per_row);
-  ESCOIN_HIP_TRY(hipGetLastError());
-  std::vector<int> cnt(M), ptr(M + 1);
-  ESCOIN_HIP_TRY(hipMemcpyAsync(cnt.data(), nnz_per_row, sizeof(int) * M, hipMemcpyDeviceToHost, s));
-  ESCOIN_HIP_TRY(hipStreamSynchronize(s));
-  ptr[0] = 0;
-  for (int i = 0; i < M; ++i) ptr[i + 1] = ptr[i] + cnt[i];
-  ESCOIN_HIP_TRY(hipMemcpyAsync(A_idx_pointer_buf, ptr.data(), sizeof(int) * (M + 1),
-                                hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(escoin_row_fill_kernel, dim3(M), dim3(64), 0, s, A, M, N,
-                     (const int *)A_idx_pointer_buf, A_nonzero_buf, A_nonzero_idx_buf);
-  ESCOIN_HIP_TRY(hipGetLastError());
-  ESCOIN_HIP_TRY(hipStreamSynchronize(s));  // ptr (host) must outlive the async copy
-  *nnz_total = ptr[M];
-  return ESCOIN_OK;
+  return guarded([&]() -> int {
+    return dense2csr_t<float>(M, N, A, nnz_per_row, A_nonzero_buf, A_idx_pointer_buf, A_nonzero_idx_buf, nnz_total, stream);
+  });
+}
+
+extern "C" int escoin_gpu_sparse_dense2csr_f64(int M, int N, const double *A, int *nnz_per_row,
+                                               double *A_nonzero_buf, int *A_idx_pointer_buf,
+                                               int *A_nonzero_idx_buf, int *nnz_total,
+                                               void *stream) {
+  return guarded([&]() -> int {
+    return dense2csr_t<double>(M, N, A, nnz_per_row, A_nonzero_buf, A_idx_pointer_buf, A_nonzero_idx_buf, nnz_total, stream);
+  });
 }

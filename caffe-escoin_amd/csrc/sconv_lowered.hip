@@ -124,6 +124,31 @@ int csrmm(int M, int N, int K, float alpha, const float *vals, const int *rowptr
 
 // Forward_gpu in conv_mode LOWERED_SPARSE: chunks of images so that the column buffer stays
 // within kColBytes (the reference lowers one image at a time into col_buffer_).
+// caffe_gpu_sparse_csrmm<double>, math_functions.cu:64-78: the same product for Dtype = double (one lane per column,
+// CSR order from zero, fp64 fused multiply-add).
+__global__ void __launch_bounds__(256) escoin_csrmm_f64_kernel(int M, int N, double alpha, const double *__restrict__ vals,
+                                                               const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                                               const double *__restrict__ B, double beta, double *__restrict__ C) {
+  const int m = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M || col >= N) return;
+  double s = 0.0;
+  for (int j = rowptr[m]; j < rowptr[m + 1]; ++j) s = fma(vals[j], B[(size_t)colidx[j] * N + col], s);
+  double r = alpha == 1.0 ? s : alpha * s;
+  if (beta != 0.0) r += beta * C[(size_t)m * N + col];
+  C[(size_t)m * N + col] = r;
+}
+
+int csrmm_f64(int M, int N, int K, double alpha, const double *vals, const int *rowptr, const int *colidx,
+              const double *B, double beta, double *C, hipStream_t stream) {
+  (void)K;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)M, 1);
+  if (grid.y > 65535u) return fail(ESCOIN_EINVAL, "csrmm_f64: more than 65535 rows");
+  hipLaunchKernelGGL(escoin_csrmm_f64_kernel, grid, dim3(256), 0, stream, M, N, alpha, vals, rowptr, colidx, B, beta, C);
+  ESCOIN_HIP_TRY(hipGetLastError());
+  return ESCOIN_OK;
+}
+
 int launch_lowered(escoin_plan *p, const float *bottom, const float *bias, float *top, int n_images,
                    hipStream_t stream) {
   const Geometry &g = p->g;

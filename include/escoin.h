@@ -25,8 +25,17 @@
  *     escoin_plan_destroy (reference: layer dtor, base_conv_layer.cpp:16-42);
  *   - thread-compatible: one plan per (host thread, device), like a Caffe layer
  *     instance (common.cpp:13-19 keeps the Caffe singleton thread-local).
- *   - there is NO CPU fallback in this library: without a HIP device every compute
- *     entry point fails with ESCOIN_ENODEVICE.
+ *   - no SILENT CPU fallback: the GPU entry points (escoin_weight_align, escoin_forward, the escoin_gpu_* helpers)
+ *     fail with ESCOIN_ENODEVICE when no HIP device is visible, they never compute on the host.  Caffe::CPU mode
+ *     (ConvolutionLayer::Forward_cpu, conv_layer.cpp:25-63) is a separate, explicit set of entry points --
+ *     escoin_weight_align_cpu / escoin_forward_cpu / escoin_cpu_* below -- implemented in this library
+ *     (csrc/sconv_cpu*.cpp) and usable on a machine without a GPU;
+ *   - Dtype: the reference instantiates the path for float and double (conv_layer.cpp:102, conv_layer.cu:75,
+ *     math_functions.cu:696-704,765-766, math_functions.cpp:178-199).  Every unsuffixed entry point is the float
+ *     one; the `_f64` twins take double.  A plan's type is fixed by the align call (weight_align[_cpu][_f64] /
+ *     set_csr[_f64]); calling the other type's forward on it is ESCOIN_ESTATE.  north_star measures fp32: double
+ *     plans run the order-preserving generic kernel on the device (fp64 vector FMA is native on gfx950) and the same
+ *     host kernel as float in CPU mode -- no LDS-tiled / generated-code / MFMA fast path.
  */
 #ifndef ESCOIN_H_
 #define ESCOIN_H_
@@ -97,8 +106,11 @@ ESCOIN_API int escoin_device_count(void);
 /* ConvolutionLayer::compute_output_shape, conv_layer.cpp:8-22. */
 ESCOIN_API int escoin_out_shape(const escoin_conv_desc *desc, int *out_h, int *out_w);
 
-/* Length in floats of the reference's shared-halo padded image
- * C(H+ph)(W+pw) + ph(W+2pw), base_conv_layer.cpp:71,596. */
+/* Length in elements of the reference's shared-halo padded image C(H+ph)(W+pw) + ph(W+2pw),
+ * base_conv_layer.cpp:71,596 -- plus pad_w elements when pad_h == 0 < pad_w: the last row's right padding is read
+ * out of the elements that follow the row, and without a bottom padding row nothing follows the last channel's last
+ * row (the reference's buffer is pad_w short there and its kernels read past it; none of its models has such a
+ * layer).  A zeroed buffer of this length is safe for escoin_gpu_sconv / escoin_cpu_sconv / copy_input_data. */
 ESCOIN_API long escoin_padded_len(const escoin_conv_desc *desc);
 
 /* LayerSetUp + Reshape: validates the geometry and creates an empty plan.
@@ -254,6 +266,80 @@ ESCOIN_API int escoin_gpu_sparse_csrmm(int M, int N, int K, int nnz, float alpha
 ESCOIN_API int escoin_gpu_sparse_dense2csr(int M, int N, const float *A, int *nnz_per_row,
                                 float *A_nonzero_buf, int *A_idx_pointer_buf,
                                 int *A_nonzero_idx_buf, int *nnz_total, void *stream);
+
+/* ---- Dtype = double on the device (conv_layer.cu:75; math_functions.cu:696-704,765-766) ----------------------
+ * Same contracts as the float entry points above.  escoin_forward_f64 runs the order-preserving generic kernel
+ * (one lane per output pixel, CSR order, fp64 fused multiply-add) in every conv_mode: its results are bit-identical to
+ * caffe_cpu_sconv<double>'s.  The aligned-form export / import is defined for float plans only. */
+ESCOIN_API int escoin_weight_align_f64(escoin_plan *plan, const double *dense_w, int w_on_device, void *stream);
+ESCOIN_API int escoin_plan_set_csr_f64(escoin_plan *plan, const int *rowptr, const int *colidx, const double *values,
+                            const int *nnz_per_group, void *stream);
+ESCOIN_API int escoin_plan_get_csr_f64(const escoin_plan *plan, int *rowptr, int *colidx, double *values, int stretched);
+ESCOIN_API int escoin_forward_f64(escoin_plan *plan, const double *bottom_dev, const double *bias_dev, double *top_dev,
+                       int n_images, void *stream);
+/* caffe_gpu_sconv<double>, copy_input_data<double>, caffe_gpu_sparse_csrmm<double>, caffe_gpu_sparse_dense2csr<double> */
+ESCOIN_API int escoin_gpu_sconv_f64(int fuse_relu, int num, const double *input, int ifmap_size, const int *rowptr,
+                         const int *colidx, const double *values, const double *bias, int height, int width,
+                         int pad_h, int pad_w, int stride_h, int stride_w, int dilation_h, int dilation_w,
+                         int kernel_h, int kernel_w, double *output, int num_oc, int num_groups, void *stream);
+ESCOIN_API int escoin_copy_input_data_f64(double *dst, const double *src, int num_channels, int height, int width,
+                               int pad_h, int pad_w, void *stream);
+ESCOIN_API int escoin_gpu_sparse_csrmm_f64(int M, int N, int K, int nnz, double alpha, const double *values,
+                                const int *rowptr, const int *colidx, const double *B, double beta, double *C,
+                                void *stream);
+ESCOIN_API int escoin_gpu_sparse_dense2csr_f64(int M, int N, const double *A, int *nnz_per_row, double *A_nonzero_buf,
+                                    int *A_idx_pointer_buf, int *A_nonzero_idx_buf, int *nnz_total, void *stream);
+
+/* ---- Caffe::CPU mode (Caffe::set_mode(Caffe::CPU)): host entry points, no HIP device needed ---------------------
+ *   ConvolutionLayer<Dtype>::Forward_cpu          conv_layer.cpp:25-63
+ *     -> BaseConvolutionLayer::forward_cpu_sconv  base_conv_layer.cpp:569-661 (pad copy :601-620, groups :626-658)
+ *        -> caffe_cpu_sconv<Dtype>                math_functions.cpp:128-176
+ *     -> forward_cpu_bias                         base_conv_layer.cpp:663-669
+ *   WeightAlign, CPU branch                       base_conv_layer.cpp:46-107
+ * Implemented in this library (csrc/sconv_cpu.cpp, sconv_cpu_kernel.cpp: AVX2 / AVX-512 register tiles over the
+ * shared-halo layout, a team of host threads over images and output channels).  Every output is
+ * fma(value_j, input_j, sum) over its row's nonzeros in CSR order from zero, + bias once afterwards, then ReLU --
+ * the arithmetic of the reference's loop nest, so results are BIT-IDENTICAL to caffe_cpu_sconv + forward_cpu_bias for
+ * float and for double, whatever the thread count.  Differences kept on purpose: the density gate that sends a layer
+ * to the dense GEMM above 50 % density (base_conv_layer.cpp:572-577) is not reproduced (the sparse kernel computes the
+ * same sums), every Caffe::ConvMode takes this path (the reference's Forward_cpu uses it for SCONV only), and bias
+ * may be NULL. */
+
+/* Which flavour of the host kernel this machine runs ("escoin_cpu_sconv_avx512" / "..._avx2"). */
+ESCOIN_API const char *escoin_cpu_kernel_name(void);
+
+/* WeightAlign() in CPU mode: dense blobs_[0] on the host -> the plan's host CSR.  No device work; a plan aligned this
+ * way serves escoin_forward_cpu only (escoin_forward needs escoin_weight_align).  Conversely escoin_forward_cpu also
+ * works on a plan aligned by escoin_weight_align / set_csr / import_aligned: the CSR is on the host either way. */
+ESCOIN_API int escoin_weight_align_cpu(escoin_plan *plan, const float *dense_w);
+ESCOIN_API int escoin_weight_align_cpu_f64(escoin_plan *plan, const double *dense_w);
+
+/* Forward_cpu body for one bottom/top pair, whole batch, host pointers; returns when the batch is done.
+ * n_threads: host threads to use (<= 0: all the process may run on).  n_images is not bounded by desc.N. */
+ESCOIN_API int escoin_forward_cpu(escoin_plan *plan, const float *bottom, const float *bias, float *top, int n_images,
+                       int n_threads);
+ESCOIN_API int escoin_forward_cpu_f64(escoin_plan *plan, const double *bottom, const double *bias, double *top,
+                           int n_images, int n_threads);
+
+/* caffe_cpu_sconv<Dtype>, math_functions.cpp:128-176 (declared include/caffe/util/math_functions.hpp:40-47): one conv
+ * group of one image on the reference's padded layout with the stretched CSR; `bias` is accepted and ignored, as there.
+ * Reads nothing past the last element an output needs; fails with ESCOIN_EINVAL if that lies at or beyond
+ * input_padded_len (the reference asserts it, :168; input_padded_len <= 0 skips the check). */
+ESCOIN_API int escoin_cpu_sconv(const float *input_padded, int in_channels, int height, int width, int pad_h, int pad_w,
+                     int stride_h, int stride_w, int dilation_h, int dilation_w, const int *rowptr,
+                     const int *colidx, const float *values, int kernel_h, int kernel_w, const float *bias,
+                     float *output, int out_channels, int input_padded_len);
+ESCOIN_API int escoin_cpu_sconv_f64(const double *input_padded, int in_channels, int height, int width, int pad_h,
+                         int pad_w, int stride_h, int stride_w, int dilation_h, int dilation_w, const int *rowptr,
+                         const int *colidx, const double *values, int kernel_h, int kernel_w, const double *bias,
+                         double *output, int out_channels, int input_padded_len);
+
+/* caffe_cpu_sparse_dense2csr<Dtype>, the hand loop of math_functions.cpp:92-105 (0-based, ascending columns;
+ * argument order as there: values, column indices, row pointers). */
+ESCOIN_API int escoin_cpu_sparse_dense2csr(int M, int N, const float *A, float *A_nonzero_buf, int *A_nonzero_idx_buf,
+                                int *A_idx_pointer_buf);
+ESCOIN_API int escoin_cpu_sparse_dense2csr_f64(int M, int N, const double *A, double *A_nonzero_buf,
+                                    int *A_nonzero_idx_buf, int *A_idx_pointer_buf);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,8 @@ def geom(C_, H, W, M, KH, KW, pad_h=0, pad_w=0, stride_h=1, stride_w=1,
 def build(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is mounted)."""
     if force or not os.path.exists(_LIB) or \
-            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "sconv_oracle.c")):
+            os.path.getmtime(_LIB) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                         for f in ("sconv_oracle.c", "sconv_oracle_f64.c")):
         subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/include/caffe/util/sconv.hpp") and \
             (force or not os.path.exists(_REF)):
@@ -40,6 +41,7 @@ def build(force=False):
 
 
 _fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _lib = None
 _ref = None
@@ -66,6 +68,15 @@ def lib():
             f = getattr(L, name)
             f.restype = C.c_int
             f.argtypes = [C.POINTER(Geom), C.c_int, _fp, _fp, C.c_void_p, C.c_int, _fp, C.c_int]
+            f = getattr(L, name + "_f64")     # Dtype = double (sconv_oracle_f64.c)
+            f.restype = C.c_int
+            f.argtypes = [C.POINTER(Geom), C.c_int, _dp, _dp, C.c_void_p, C.c_int, _dp, C.c_int]
+        L.oracle_sconv_f64.restype = None
+        L.oracle_sconv_f64.argtypes = [_dp] + [C.c_int] * 9 + [_ip, _ip, _dp, C.c_int, C.c_int, _dp, C.c_int]
+        L.oracle_dense2csr_f64.restype = C.c_int
+        L.oracle_dense2csr_f64.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip, _ip]
+        L.oracle_pad_input_f64.restype = None
+        L.oracle_pad_input_f64.argtypes = [C.POINTER(Geom), _dp, _dp]
         _lib = L
     return _lib
 
@@ -162,6 +173,37 @@ def _bias_ptr(bias):
         return None, None
     b = np.ascontiguousarray(bias, np.float32)
     return b, b.ctypes.data_as(C.c_void_p)
+
+
+def conv_forward_f64(g, bottom, weights, bias=None, relu=False, threads=1, gate=False):
+    """conv_forward for Dtype = double (the same source text compiled with float read as double)."""
+    bottom = np.ascontiguousarray(bottom, np.float64)
+    weights = np.ascontiguousarray(weights, np.float64)
+    N = bottom.shape[0]
+    oh, ow = out_hw(g)
+    top = np.zeros((N, g.M, oh, ow), np.float64)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float64)
+    bp = None if b is None else b.ctypes.data_as(C.c_void_p)
+    fn = lib().oracle_conv_forward_f64 if gate else lib().oracle_conv_forward_nogate_f64
+    rc = fn(C.byref(g), N, bottom.ravel(), weights.ravel(), bp, int(relu), top.ravel(), threads)
+    if rc != 0:
+        raise MemoryError("oracle_conv_forward_f64 failed")
+    return top
+
+
+def sconv_f64(g, padded, cin, rowptr, colidx, values, mout):
+    """One image / one group through the restated caffe_cpu_sconv<double>."""
+    oh, ow = out_hw(g)
+    out = np.zeros(mout * oh * ow, np.float64)
+    lib().oracle_sconv_f64(padded, cin, g.H, g.W, g.pad_h, g.pad_w, g.stride_h, g.stride_w,
+                           g.dil_h, g.dil_w, rowptr, colidx, values, g.KH, g.KW, out, mout)
+    return out.reshape(mout, oh, ow)
+
+
+def pad_input_f64(g, image):
+    buf = np.zeros(padded_len(g), np.float64)
+    lib().oracle_pad_input_f64(C.byref(g), np.ascontiguousarray(image, np.float64).ravel(), buf)
+    return buf
 
 
 def conv_forward(g, bottom, weights, bias=None, relu=False, threads=1, gate=True):

@@ -1,6 +1,6 @@
 """C-ABI host logic without a GPU: the library loads, exports every symbol include/escoin.h
-declares, validates geometry like LayerSetUp/Reshape, and FAILS LOUDLY (no CPU fallback)
-when a compute entry point is reached on a machine without a HIP device."""
+declares, validates geometry like LayerSetUp/Reshape, and its GPU entry points FAIL LOUDLY (no silent
+fallback) on a machine without a HIP device; Caffe::CPU mode is explicit (tests/test_cpu_mode.py)."""
 import ctypes as C
 import os
 import re
@@ -99,16 +99,31 @@ def test_forward_before_align_is_a_state_error(pkg):
     assert rc == -1
 
 
-def test_no_cpu_fallback_fails_loudly_without_device(pkg, synth):
+def test_gpu_entry_points_fail_loudly_without_device_and_cpu_mode_is_explicit(pkg, synth, oracle):
+    """No SILENT fallback: without a HIP device the GPU entry points return ESCOIN_ENODEVICE and compute nothing.
+    Caffe::CPU mode is a separate, explicit pair of entry points of the same library (tests/test_cpu_mode.py) -- a
+    plan whose GPU align failed is still not a GPU plan."""
     if not _no_gpu(pkg):
         pytest.skip("a HIP device is visible")
     s = synth.lenet_conv2(N=1)[0]
+    w = synth.pruned_weights(s, 1)
     plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
     with pytest.raises(pkg.EscoinError) as e:
-        plan.weight_align(synth.pruned_weights(s, 1))
+        plan.weight_align(w)
     assert "no HIP device" in str(e.value)
+    with pytest.raises(pkg.EscoinError) as e:
+        plan.weight_align(w.astype(np.float64))
+    assert "no HIP device" in str(e.value)
+    rc = pkg.lib().escoin_forward(plan._h, C.c_void_p(16), None, C.c_void_p(16), 1, None)
+    assert rc == -4                                   # still not aligned for the device: forward refuses
     # math_functions-level entry points validate their arguments on the host
     assert pkg.lib().escoin_gpu_stretch(None, None, 0, 1, 1, 0, 0, 1, 1, None) == -1
+    # the explicit CPU mode works on the same machine, same library
+    plan.weight_align_cpu(w)
+    x, b = synth.activations(s, 2), synth.bias_vector(s, 3)
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, s.dil_h, s.dil_w, s.group)
+    assert np.array_equal(plan.forward_cpu(x, b), oracle.conv_forward(g, x, w, b, gate=False))
+    assert pkg.cpu_kernel_name().startswith("escoin_cpu_sconv_")
 
 
 def test_set_csr_validates_on_host(pkg):

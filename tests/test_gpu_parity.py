@@ -812,6 +812,9 @@ def test_forward_is_capturable_into_a_hip_graph(pkg, oracle, synth, torch_cuda):
              (synth.shape("g1", 6, 64, 7, 7, 72, 1, sparsity=0.95), pkg.KERNEL_AUTO, {"tiling_batch": 256}),
              (synth.shape("gs", 4, 16, 12, 12, 24, 3, pad=1, sparsity=0.8), pkg.KERNEL_TILED, {}),
              (synth.shape("gd", 3, 32, 14, 14, 64, 1, sparsity=0.0), pkg.KERNEL_DENSE, {}),
+             # a dense pointwise layer whose launch splits K across workgroups (stream-K: 392 tiles on 512 slots); its
+             # workspace is allocated at WeightAlign, so even its FIRST forward may be the captured one
+             (synth.shape("gk", 64, 1024, 7, 7, 512, 1, bias=True, sparsity=0.0), pkg.KERNEL_DENSE, {}),
              (synth.shape("gg", 3, 8, 9, 9, 12, 3, pad=1, stride=2, sparsity=0.9), pkg.KERNEL_GENERIC, {})]
     layers = []
     for k, (s, kernel, opts) in enumerate(cases):
@@ -828,11 +831,14 @@ def test_forward_is_capturable_into_a_hip_graph(pkg, oracle, synth, torch_cuda):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        step()                      # warm-up outside the capture
+        for s, plan, w, b, x, bd, y in layers:
+            if s.name != "gk":      # warm-up outside the capture -- except the stream-K layer: its first forward IS the captured one
+                plan.forward(x, bd, y)
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         step()
+    assert [p_.stat("streamk") for s_, p_, *_ in layers if s_.name == "gk"] == [1]
     for rnd in range(2):            # two replays on different bottom data
         for k, (s, plan, w, b, x, bd, y) in enumerate(layers):
             x.copy_(torch.from_numpy(synth.activations(s, 8300 + 10 * rnd + k)).to(dev))
@@ -843,6 +849,9 @@ def test_forward_is_capturable_into_a_hip_graph(pkg, oracle, synth, torch_cuda):
             geo = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, 1, 1, 1)
             want = oracle.conv_forward(geo, synth.activations(s, 8300 + 10 * rnd + k), w, b, gate=False)
             assert rel_err(y.cpu().numpy(), want) <= TOL, (s.name, plan.kernel_name, rnd)
+            # (a stream-K give-up inside a replay is not seen by escoin_forward -- the host replays, it does not call;
+            #  the sticky word is what a replaying host polls)
+            assert plan.stat("streamk_gave_up") == 0
     for s, plan, *_ in layers:
         plan.close()
 
