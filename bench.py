@@ -411,40 +411,186 @@ def cpu_baseline(oracle, synth, shapes, budget_s):
     return out
 
 
-def traffic_per_layer(workload):
-    """{layer name: HBM bytes per launch} from the committed PMC summary (tools/save_profile.py breaks the
-    counters down by dispatch order), or {}."""
+WORKLOAD_DEFAULTS = {"resnet50": (256, 90), "alexnet": (128, 80), "googlenet": (256, 95), "lenet": (64, 50)}
+
+
+def _traffic_blob(workload, batch, sparsity_pct):
+    """The committed PMC summary profiles/traffic_<workload>.json IF it was collected on this very configuration:
+    same workload, same per-GPU batch, same weight sparsity.  The file carries `_batch` / `_sparsity_pct`
+    (tools/save_profile.py writes them from the bench line of the profiled run); a file from before round 6 has
+    neither and was collected on the workload's default configuration (WORKLOAD_DEFAULTS).  Anything else -- a
+    --global-batch 2048 line, a sparsity sweep point -- has NO matching entry and gets None: a ratio of one
+    configuration's traffic over another's algorithmic bytes is not a measurement (0.211)."""
     path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     try:
-        return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(path)).get("_per_layer", {}).items()}
+        blob = json.load(open(path))
+    except Exception:
+        return None, path
+    dflt = WORKLOAD_DEFAULTS.get(workload, (None, None))
+    have_batch = blob.get("_batch", dflt[0])
+    have_sp = blob.get("_sparsity_pct", dflt[1])
+    if have_batch is None or have_sp is None or int(have_batch) != int(batch) or int(round(have_sp)) != int(round(sparsity_pct)):
+        return None, path
+    return blob, path
+
+
+def traffic_per_layer(workload, batch=None, sparsity_pct=None):
+    """{layer name: HBM bytes per launch} from the committed PMC summary of THIS configuration (tools/save_profile.py
+    breaks the counters down by dispatch order), or {}."""
+    dflt = WORKLOAD_DEFAULTS.get(workload, (None, None))
+    blob, _ = _traffic_blob(workload, dflt[0] if batch is None else batch, dflt[1] if sparsity_pct is None else sparsity_pct)
+    if not blob:
+        return {}
+    try:
+        return {k: v["hbm_bytes_per_launch"] for k, v in blob.get("_per_layer", {}).items()}
     except Exception:
         return {}
 
 
-def traffic_with_provenance(workload, kernel_name):
+def traffic_with_provenance(workload, kernel_name, batch=None, sparsity_pct=None):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (FETCH_SIZE x 2
     + WRITE_SIZE, MI355X_MICROARCH.md); collected in a separate rocprofv3 --pmc run
-    (tools/profile.sh), so it comes with the file and the commit that file was last written in."""
-    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
-    if not os.path.exists(path):
+    (tools/profile.sh), so it comes with the file and the commit that file was last written in.
+    (None, None) when the file was collected on another batch or sparsity."""
+    dflt = WORKLOAD_DEFAULTS.get(workload, (None, None))
+    batch = dflt[0] if batch is None else batch
+    sparsity_pct = dflt[1] if sparsity_pct is None else sparsity_pct
+    blob, path = _traffic_blob(workload, batch, sparsity_pct)
+    if not blob:
         return None, None
-    try:
-        blob = json.load(open(path))
-        value = blob.get(kernel_name)
-    except Exception:
+    value = blob.get(kernel_name)
+    if value is None:
         return None, None
     commit = blob.get("_commit")
-    if commit:      # written by tools/save_profile.py next to the numbers
-        return value, {"file": os.path.relpath(path, ROOT), "commit": commit, "saved": blob.get("_saved"),
-                       "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE"}
-    try:
-        commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", path],
-                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                                timeout=10).stdout.decode().strip() or None
-    except Exception:
-        pass
-    return value, {"file": os.path.relpath(path, ROOT), "commit": commit,
-                   "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE"}
+    how = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE"
+    if not commit:
+        try:
+            commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", path],
+                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                    timeout=10).stdout.decode().strip() or None
+        except Exception:
+            pass
+    return value, {"file": os.path.relpath(path, ROOT), "commit": commit, "saved": blob.get("_saved"),
+                   "batch": int(batch), "sparsity_pct": int(round(sparsity_pct)), "how": how}
+
+
+def measure_config(be, pkg, synth, oracle, workload, sparsity, cache, target_ms=150.0, settle_ms=100.0):
+    """One more single-GPU configuration, timed AFTER (never inside) the headline region: the same step (every layer of
+    the workload, own bottom / top pair per layer, one stream), the same event accounting and the same parity check
+    against the oracle.  Returns a compact sub-record for `other_configs` / `sparsity_sweep`.
+      ms_per_step   K steps between two HIP events on the launch stream, K chosen for ~target_ms of device time
+      frac          the step's algorithmic bytes / ms_per_step / 8 TB/s  (HBM roofline fraction of the whole step)
+      binding_frac  sum over layers of max(bytes / 8 TB/s, flops / 157.3 TF) / ms_per_step
+      per_layer     from one extra step with an event between every two launches (after the timed steps)"""
+    torch = be.torch
+    shapes, wl_name = workload_layers(synth, workload, None, sparsity)
+    batch = shapes[0].N
+    layers, _, setup = build_layers(be, pkg, synth, shapes, 0, 1, None, False)
+    key = (workload, batch)
+    if key not in cache:                 # the synthetic batch does not depend on the sparsity: one per workload
+        cache.clear()                    # (one workload's inputs at a time: the sweep runs workload by workload)
+        cache[key] = [device_images(be, s, si, 0, batch) for si, s in enumerate(shapes)]
+    shape_bottoms = cache[key]
+    bottoms, tops, used = [], [], set()
+    for (s, plan, bias, si, lid) in layers:
+        bottoms.append(shape_bottoms[si] if si not in used else shape_bottoms[si].clone())
+        used.add(si)
+        tops.append(torch.empty((batch, s.M) + tuple(synth.out_hw(s)), device=be.device))
+
+    def step(events=None):
+        for li, (s, plan, bias, si, lid) in enumerate(layers):
+            plan.forward(bottoms[li], bias, tops[li])
+            if events is not None:
+                events[li + 1].record()
+
+    def timed(k):
+        e0, e1 = be.event(), be.event()
+        e0.record()
+        for _ in range(k):
+            step()
+        e1.record()
+        be.synchronize()
+        return e0.elapsed_time(e1) / k
+    be.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        step()
+        be.synchronize()
+    est = timed(3)
+    k = int(min(400, max(10, target_ms / max(est, 1e-3))))
+    runs = sorted(timed(k) for _ in range(3))
+    ms = runs[1]                                                   # median of three regions of k steps
+    ev = [be.event() for _ in range(len(layers) + 1)]
+    ev[0].record()
+    step(ev)
+    be.synchronize()
+    layer_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(len(layers))]
+    scale = ms / max(1e-9, sum(layer_ms))                          # (events between launches cost time: normalised to the plain step)
+    parity = parity_check(be, oracle, synth, layers, bottoms, tops)
+    per_kernel, per_shape = {}, {}
+    for li, (s, plan, bias, si, lid) in enumerate(layers):
+        per_kernel[plan.kernel_name] = per_kernel.get(plan.kernel_name, 0.0) + layer_ms[li]
+        per_shape.setdefault(si, []).append(layer_ms[li] * scale)
+    dom = max(per_kernel.items(), key=lambda kv: kv[1])
+    byt = sum(synth.algorithmic_bytes(s, batch) * s.count for s in shapes)
+    flo = sum(synth.flops(s, batch) * s.count for s in shapes)
+    t_bind = sum(max(synth.algorithmic_bytes(s, batch) / (HBM_PEAK_GBS * 1e9),
+                     synth.flops(s, batch) / (FP32_VECTOR_TFLOPS * 1e12)) * s.count for s in shapes)
+    per_layer = []
+    for si, s in enumerate(shapes):
+        m = float(np.mean(per_shape[si]))
+        b1, f1 = synth.algorithmic_bytes(s, batch), synth.flops(s, batch)
+        per_layer.append({"layer": s.name, "count": s.count, "us": round(m * 1e3, 1),
+                          "hbm_frac": round(b1 / (HBM_PEAK_GBS * 1e9) / (m * 1e-3), 4),
+                          "binding_frac": round(max(b1 / (HBM_PEAK_GBS * 1e9), f1 / (FP32_VECTOR_TFLOPS * 1e12)) / (m * 1e-3), 4)})
+    rec = {"workload": workload,
+           "config": "%s @%d%% sparsity, batch %d, fp32" % (wl_name, round(100 * shapes[0].sparsity), batch),
+           "sparsity_pct": int(round(100 * shapes[0].sparsity)), "batch": batch,
+           "ms_per_step": round(ms, 4), "ms_per_step_regions": [round(v, 4) for v in runs], "steps": k,
+           "images_per_s": round(batch / (ms * 1e-3), 1),
+           "frac": round(byt / (HBM_PEAK_GBS * 1e9) / (ms * 1e-3), 4),
+           "binding_frac": round(t_bind / (ms * 1e-3), 4),
+           "alg_GBps": round(byt / (ms * 1e-3) / 1e9, 1), "sparse_TFLOPs": round(flo / (ms * 1e-3) / 1e12, 2),
+           "parity_max_rel_err": float("%.3g" % parity),
+           "dominant_kernel": dom[0], "dominant_kernel_share": round(dom[1] / max(1e-9, sum(layer_ms)), 3),
+           "layers_per_step": len(layers), "weight_align_ms": round(sum(setup["align_ms"]), 1),
+           "per_layer": per_layer}
+    if parity > 1e-4:
+        rec["parity_failed"] = True
+    for (s, plan, bias, si, lid) in layers:
+        plan.close()
+    del bottoms, tops
+    return rec
+
+
+def measure_extras(be, pkg, synth, oracle, budget_s):
+    """every 1-GPU config of BASELINE.json and north_star's 60-95 % sweep in the driver-run line.
+    other_configs: AlexNet conv2-5 @80 % N=128 (configs[1]), GoogLeNet 1x1 @95 % N=256 (configs[4]), LeNet conv2
+    (configs[0]'s layer on the GPU).  sparsity_sweep: the ResNet-50 and AlexNet sets at 60 / 70 / 80 / 95 % (ResNet @90 %
+    is the headline itself, AlexNet @80 % is other_configs.alexnet -- both are repeated in the sweep table by reference).
+    Stops starting new configurations when the budget is spent (what was skipped is listed)."""
+    t0 = time.perf_counter()
+    cache, other, sweep, skipped = {}, {}, [], []
+    plan_list = [("alexnet", None, other), ("alexnet", 0.6, sweep), ("alexnet", 0.7, sweep), ("alexnet", 0.95, sweep),
+                 ("lenet", None, other),
+                 ("googlenet", None, other),
+                 ("resnet50", 0.6, sweep), ("resnet50", 0.7, sweep), ("resnet50", 0.8, sweep), ("resnet50", 0.95, sweep)]
+    for workload, sparsity, dest in plan_list:
+        if time.perf_counter() - t0 > budget_s:
+            skipped.append("%s@%s" % (workload, "default" if sparsity is None else int(sparsity * 100)))
+            continue
+        t1 = time.perf_counter()
+        rec = measure_config(be, pkg, synth, oracle, workload, sparsity, cache)
+        rec["wall_s"] = round(time.perf_counter() - t1, 2)
+        log("  extra %-10s @%2d%%  %8.4f ms/step  %10.1f img/s  frac %.3f  binding %.3f  parity %.2g  (%s, %.1f s)" %
+            (workload, rec["sparsity_pct"], rec["ms_per_step"], rec["images_per_s"], rec["frac"], rec["binding_frac"],
+             rec["parity_max_rel_err"], rec["dominant_kernel"], rec["wall_s"]))
+        if dest is other:
+            other[workload] = rec
+        else:
+            sweep.append(rec)
+    cache.clear()
+    return other, sweep, skipped, round(time.perf_counter() - t0, 1)
 
 
 def test_be(be):
@@ -519,18 +665,30 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
             if events is not None:
                 events[li + 1].record()
 
-    # The chip's clocks take tens of milliseconds of load to settle (the first 100 launches of a layer run
-    # 10-15 % slower than the next hundred): a short run's W warm-up steps may be over before that.  Before
-    # them, untimed and outside the W + K steps the command asks for, the same step runs for a fixed
-    # wall-clock time.
+    # Order of the run: W warm-up steps, then K steps timed COLD (`ms_per_step_cold`: what a caller gets who does exactly
+    # what the command line says -- W untimed steps, K timed ones, nothing else), then the settle loop, then the R timed
+    # regions `value` is computed from.  The chip's clocks take tens of milliseconds of load to settle (the first 100
+    # launches of a layer run 10-15 % slower than the next hundred): with `--warmup 5` the cold region is over before
+    # that.  The settle loop runs the same step untimed for a fixed wall-clock time, outside the W + K steps the command
+    # asks for and declared in the JSON line (`settle_ms`); both numbers are printed so a caller sees both.
+    for _ in range(args.warmup):
+        step()
+    cold_ms = None
+    if not test_be(be):
+        e0, e1 = be.event(), be.event()
+        be.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        be.synchronize()
+        cold_ms = e0.elapsed_time(e1) / args.steps
     if args.settle_ms > 0:
         be.synchronize()
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             step()
             be.synchronize()
-    for _ in range(args.warmup):
-        step()
     # Events inside the timed region: ONE per step boundary in every step, and one between every two
     # launches in a SAMPLE of the steps (10 of the default 100, 2 of a run of 20).  An event
     # between two kernels is not free -- 1.5 us per launch on the ResNet set, 2.9 us on GoogLeNet's 39
@@ -625,7 +783,8 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         i["ms"] += m
         i["launches"] += 1
     per_layer, seen = [], {}
-    layer_traffic = traffic_per_layer(args.workload)
+    sparsity_pct = round(100 * shapes[0].sparsity)
+    layer_traffic = traffic_per_layer(args.workload, per_gpu_batch, sparsity_pct)
     seen_raw = {}
     for li, (s, plan, bias, si, lid) in enumerate(layers):
         seen.setdefault(si, []).append(layer_ms[li])
@@ -652,7 +811,7 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     # HBM traffic per launch: the instantiations' PMC figures weighted by their launches
     traffic, provenance, tw = None, None, 0
     for iname, iv in dom["inst"].items():
-        tv, pv = traffic_with_provenance(args.workload, iname)
+        tv, pv = traffic_with_provenance(args.workload, iname, per_gpu_batch, sparsity_pct)
         if tv is None:
             traffic = None
             break
@@ -699,6 +858,8 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
         "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        # the K steps right after the W warm-up steps, BEFORE the settle loop (clocks not yet settled)
+        "ms_per_step_cold": None if cold_ms is None else round(cold_ms, 4),
         # R timed regions of K steps each; value / ms_per_step are the MEDIAN region's
         "repeats": len(regions), "ms_per_step_min": round(min(region_ms), 4),
         "ms_per_step_max": round(max(region_ms), 4),
@@ -707,7 +868,8 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s @%d%% sparsity, batch %d/GPU, fp32" %
                                (wl_name, round(100 * shapes[0].sparsity), per_gpu_batch),
-                   "global_batch": global_batch, "layers_per_step": len(layers),
+                   "global_batch": global_batch, "per_gpu_batch": per_gpu_batch, "sparsity_pct": sparsity_pct,
+                   "workload_key": args.workload, "layers_per_step": len(layers),
                    "sparsity_dist": getattr(args, "sparsity_dist", "uniform"),
                    "kernel": args.kernel, "stream_stores": bool(getattr(args, "stream_stores", False)),
                    "streams": n_streams,
@@ -741,6 +903,30 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     if parity > 1e-4 or (cross is not None and cross > 1e-5):
         out["parity_failed"] = True
         log("PARITY FAILURE: parity_max_rel_err=%g cross_rank=%r" % (parity, cross))
+    if world == 1 and not dist_on and not test_be(be) and not args.no_extras and args.workload == "resnet50" and \
+            args.sparsity is None and args.batch is None and not strong and args.kernel == "auto" and n_streams == 1:
+        # the other single-GPU configurations and the sparsity sweep, AFTER the headline region (its buffers freed first)
+        del bottoms, tops, shape_bottoms
+        for (s_, plan_, *_rest) in layers:
+            plan_.close()
+        torch.cuda.empty_cache()
+        log("other configs + sparsity sweep (after the timed region, budget %.0f s):" % args.extras_budget)
+        other, sweep, skipped, took = measure_extras(be, pkg, synth, oracle, args.extras_budget)
+        headline = {"workload": "resnet50", "sparsity_pct": sparsity_pct, "batch": per_gpu_batch,
+                    "ms_per_step": out["ms_per_step"], "images_per_s": out["value"],
+                    "frac": round(total_alg / (HBM_PEAK_GBS * 1e9) / (ms_per_step * 1e-3), 4),
+                    "binding_frac": round(t_bind / (ms_per_step * 1e-3), 4),
+                    "parity_max_rel_err": out["parity_max_rel_err"], "dominant_kernel": dom_label, "same_as": "the headline line"}
+        out["other_configs"] = other
+        table = list(sweep) + [headline]
+        if "alexnet" in other:
+            table.append(dict({k: v for k, v in other["alexnet"].items() if k != "per_layer"}, same_as="other_configs.alexnet"))
+        out["sparsity_sweep"] = sorted(table, key=lambda r: (r["workload"], r["sparsity_pct"]))
+        out["extras"] = {"wall_s": took, "skipped": skipped,
+                         "note": "timed after the headline region, never inside it; K steps between two HIP events on the "
+                                 "launch stream, median of 3 regions; same synthetic data rules, parity vs the oracle per config"}
+        if any(r.get("parity_failed") for r in list(other.values()) + sweep):
+            out["parity_failed"] = True
     if world == 1 and not args.no_cpu:
         log("cpu_baseline (bounded sample, %.0f s budget):" % args.cpu_budget)
         out["cpu_baseline"] = cpu_baseline(oracle, synth, shapes, args.cpu_budget)
@@ -771,6 +957,10 @@ def parse_args(argv=None):
                     help="auto = generated code (jit) where available; tiled = the LDS-staged stream kernel")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds for the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the other single-GPU configurations and the sparsity sweep that the default 1-GPU ResNet run "
+                         "times after its headline region (profiling runs: the kernel averages then are the headline's)")
+    ap.add_argument("--extras-budget", type=float, default=55.0, help="seconds for other_configs + sparsity_sweep")
     ap.add_argument("--stream-stores", action="store_true",
                     help="plan option stream_stores = 1: pointwise layers write their top blob with non-temporal "
                          "stores (the layers of a step have no consumer here; a net's next layer reads the blob, "

@@ -522,6 +522,12 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Zeroes the stream-K flag words before a launch (see launch_dense for why this is not a memset).
+__global__ void __launch_bounds__(256) escoin_sk_clear_kernel(unsigned *flag, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = 0u;
+}
+
 const char *dense_kernel_name() { return "escoin_dense_mfma_kernel"; }
 
 // Layout of the dense weight matrix on the device: rows of dense_lda(K) floats (whole k-steps,
@@ -684,7 +690,12 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
     const size_t flag_bytes = ((size_t)(n_wg + 1) * 4 + 15) / 16 * 16;
     a.sk_flag = reinterpret_cast<unsigned *>(p->d_sk_ws);
     a.sk_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(p->d_sk_ws) + flag_bytes);
-    ESCOIN_HIP_TRY(hipMemsetAsync(a.sk_flag, 0, flag_bytes, stream));
+    // re-arm the flags with a KERNEL, not hipMemsetAsync: captured into a HIP graph, a memset node of this size
+    // (2064 bytes) left garbage in its last 16 bytes -- the give-up word -- from the second replay on (ROCm 7.2, MI355X;
+    // tools/dbg/sk_graph.py: eager launches and the first replay read 0, later replays 0xDB3F....), while kernel nodes
+    // replay exactly
+    hipLaunchKernelGGL(escoin_sk_clear_kernel, dim3(((unsigned)(flag_bytes / 4) + 255) / 256), dim3(256), 0, stream, a.sk_flag,
+                       (int)(flag_bytes / 4));
   }
   p->sk_used = streamk;
   dim3 grid((unsigned)n_wg, 1, 1);

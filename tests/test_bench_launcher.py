@@ -127,3 +127,26 @@ def test_every_tool_script_compiles():
     for f in files:
         with open(f) as src:
             compile(src.read(), f, "exec")
+
+
+def test_traffic_bookkeeping_is_keyed_by_workload_batch_and_sparsity():
+    """roofline.traffic comes from a committed PMC file; it only counts for the configuration it was collected on
+    (a --global-batch 2048 line reported batch-256 traffic over batch-2048 bytes, 0.211)."""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    path = os.path.join(ROOT, "profiles", "traffic_resnet50.json")
+    blob = json.load(open(path))
+    kernel = [k for k in blob if k.startswith("escoin_sconv")][0]
+    batch = blob.get("_batch", 256)
+    sp = blob.get("_sparsity_pct", 90)
+    v, prov = bench.traffic_with_provenance("resnet50", kernel, batch, sp)
+    assert v == blob[kernel] and prov["batch"] == batch and prov["sparsity_pct"] == sp
+    # a batch the file does not have -> null, not a ratio of mismatched quantities
+    assert bench.traffic_with_provenance("resnet50", kernel, 2048, sp) == (None, None)
+    assert bench.traffic_with_provenance("resnet50", kernel, batch, 60) == (None, None)
+    assert bench.traffic_per_layer("resnet50", 2048, sp) == {}
+    assert bench.traffic_per_layer("resnet50", batch, sp)        # the matching configuration has its per-layer table
+    assert bench.traffic_with_provenance("no_such_workload", kernel, 1, 1) == (None, None)
