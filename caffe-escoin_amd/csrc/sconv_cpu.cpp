@@ -12,9 +12,14 @@
 //
 // Threads: the reference's g++ build runs the batch loop serially and its ICC build parallelises it over images with
 // per-thread padded buffers (conv_layer.cpp:41-44, base_conv_layer.cpp:72-75,605-608).  Here a team of n_threads
-// std::threads takes (image, slice of output channels) items from a shared counter, every thread with its own padded
-// buffer; when the batch has fewer images than threads the output channels of an image are split instead.
+// threads (the caller + a process-wide pool of parked std::threads) takes (image, slice of output channels) items from
+// a shared counter, every thread with its own padded buffer; when the batch has fewer images than threads the output
+// channels of an image are split instead.
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <mutex>
@@ -52,47 +57,119 @@ static void run_group(const GroupJob<T> &job) {
     run_group_avx2<T>(job);
 }
 
-// Runs body(tid, item) for item = 0 .. n_items-1 on n_threads threads (the caller is thread 0).  The first exception
-// any thread throws stops the hand-out and is rethrown on the caller after every thread has been joined: nothing
-// crosses the C ABI (the entry points run inside guarded()), nothing calls std::terminate.
-template <class F>
-static void team(int n_threads, int n_items, F &&body) {
-  if (n_threads > n_items) n_threads = n_items;
-  if (n_threads < 1) n_threads = 1;
-  std::atomic<int> next(0);
-  std::atomic<bool> stop(false);
-  std::exception_ptr first;
-  std::mutex first_mu;
-  auto worker = [&](int tid) {
+// The host threads of the CPU mode: one pool per process, grown on demand, its threads parked on a condition variable
+// between calls.  (Starting fresh std::threads per call was measured first: a new thread starts on its parent's core
+// and the scheduler spreads the team one thread per 4 ms tick -- a 40 ms forward then ran on little more than one core.
+// Parked threads stay where the balancer put them.)  One team job runs at a time; a second host thread calling in
+// waits for the pool (plans are thread-compatible, the pool is thread-safe).
+class Pool {
+ public:
+  static Pool &get() {
+    static Pool pool;
+    return pool;
+  }
+  // Runs fn(tid, item) for item = 0 .. n_items-1 on n_threads threads (the caller is thread 0).  The first exception
+  // any thread throws stops the hand-out and is rethrown on the caller after the job has drained: nothing crosses the
+  // C ABI (the entry points run inside guarded()), nothing calls std::terminate.
+  template <class F>
+  void run(int n_threads, int n_items, F &&fn) {
+    if (n_items < 1) return;
+    if (n_threads > n_items) n_threads = n_items;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads == 1) {            // the caller alone: no pool, no lock -- host threads with one-thread calls run side by side
+      for (int item = 0; item < n_items; ++item) fn(0, item);
+      return;
+    }
+    std::lock_guard<std::mutex> one_job(job_mu_);
+    Job job;
+    job.n_items = n_items;
+    job.call = [&fn](int tid, int item) { fn(tid, item); };
+    if (n_threads > 1) {
+      std::unique_lock<std::mutex> lk(mu_);
+      try {
+        while ((int)workers_.size() < n_threads - 1) {
+          const int id = (int)workers_.size();
+          workers_.emplace_back([this, id] { worker_main(id); });
+        }
+      } catch (...) {   // thread creation failed: the threads that exist share the items with the caller
+        if (getenv("ESCOIN_VERBOSE"))
+          fprintf(stderr, "[escoin] cpu pool: only %zu of %d threads could be started\n", workers_.size() + 1, n_threads);
+      }
+      job.helpers = std::min((int)workers_.size(), n_threads - 1);
+      job.pending = job.helpers;
+      job_ = &job;
+      ++generation_;
+      lk.unlock();
+      wake_.notify_all();
+    }
+    work(job, 0);
+    if (job.helpers > 0) {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_.wait(lk, [&] { return job.pending == 0; });
+      job_ = nullptr;
+    }
+    if (job.first) std::rethrow_exception(job.first);
+  }
+
+ private:
+  struct Job {
+    std::function<void(int, int)> call;
+    std::atomic<int> next{0};
+    std::atomic<bool> stop{false};
+    int n_items = 0, helpers = 0, pending = 0;
+    std::exception_ptr first;
+    std::mutex first_mu;
+  };
+  static void work(Job &job, int tid) {
     try {
       for (;;) {
-        if (stop.load(std::memory_order_relaxed)) return;
-        const int item = next.fetch_add(1);
-        if (item >= n_items) return;
-        body(tid, item);
+        if (job.stop.load(std::memory_order_relaxed)) return;
+        const int item = job.next.fetch_add(1);
+        if (item >= job.n_items) return;
+        job.call(tid, item);
       }
     } catch (...) {
-      stop.store(true);
-      std::lock_guard<std::mutex> lk(first_mu);
-      if (!first) first = std::current_exception();
+      job.stop.store(true);
+      std::lock_guard<std::mutex> lk(job.first_mu);
+      if (!job.first) job.first = std::current_exception();
     }
-  };
-  struct Joiner {
-    std::vector<std::thread> t;
-    ~Joiner() {
-      for (auto &th : t)
-        if (th.joinable()) th.join();
-    }
-  } pool;
-  try {
-    pool.t.reserve((size_t)n_threads);
-    for (int i = 1; i < n_threads; ++i) pool.t.emplace_back(worker, i);
-  } catch (...) {   // thread creation failed: the threads that exist finish the items together with the caller
   }
-  worker(0);
-  for (auto &th : pool.t) th.join();
-  pool.t.clear();
-  if (first) std::rethrow_exception(first);
+  void worker_main(int id) {
+    unsigned long seen = 0;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      wake_.wait(lk, [&] { return quit_ || (generation_ != seen && job_ != nullptr); });
+      if (quit_) return;
+      seen = generation_;
+      Job *job = job_;
+      if (id >= job->helpers) continue;      // this job runs on fewer threads than the pool has
+      lk.unlock();
+      work(*job, id + 1);
+      lk.lock();
+      if (--job->pending == 0) done_.notify_all();
+    }
+  }
+  Pool() {}
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    wake_.notify_all();
+    for (auto &t : workers_)
+      if (t.joinable()) t.join();
+  }
+  std::mutex job_mu_, mu_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread> workers_;
+  Job *job_ = nullptr;
+  unsigned long generation_ = 0;
+  bool quit_ = false;
+};
+
+template <class F>
+static void team(int n_threads, int n_items, F &&body) {
+  Pool::get().run(n_threads, n_items, body);
 }
 
 static int resolve_threads(int n_threads) {
