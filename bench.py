@@ -161,57 +161,89 @@ def build_layers(be, pkg, synth, shapes, rank, world, args=None, dist_on=None):
         warm.close()
         again.close()
         setup["first_load_ms"] = max(0.0, t_first - t_again)
+    # ---- phase 1: every layer gets a plan; rank 0 aligns it from the dense weights --------------------------------
+    entries = []                       # [shape, plan, shape index, layer id]
     for si, s in enumerate(shapes):
         for rep in range(s.count):
             plan = be.make_plan(s)
-            mg = s.M // s.group
             if rank == 0:
                 w = synth.pruned_weights(s, layer_weight_seed(lid), WEIGHT_DIST)
                 t0 = time.perf_counter()
                 plan.weight_align(w)
                 be.synchronize()
                 setup["align_ms"].append((time.perf_counter() - t0) * 1e3)
-            if dist_on:
-                be.synchronize()
-                t0 = time.perf_counter()
-                # what travels: the ALIGNED form (CSR + channel deal + unit table + code object, one blob:
-                # escoin_plan_export_aligned) where the plan has one -- a receiver then loads the code rank 0
-                # generated (import_aligned) instead of generating its own from the CSR (set_csr: 5-125 ms per
-                # layer) --, the CSR alone otherwise (--broadcast csr, or a backend without code)
-                aligned = getattr(args, "broadcast", "aligned") == "aligned" and hasattr(plan, "export_aligned")
-                if aligned:
-                    got = pkg.shard.broadcast_blob(plan.export_aligned() if rank == 0 else None, src=0, device=be.device)
-                else:
-                    csr = plan.get_csr() if rank == 0 else None
-                    got = pkg.shard.broadcast_csr(csr, s.group, s.group * (mg + 1), synth.nnz_of(s),
-                                                  src=0, device=be.device)
-                be.synchronize()
-                t_bcast += time.perf_counter() - t0
-                if rank != 0 or loopback:
-                    if loopback:
-                        plan.close()
-                        plan = be.make_plan(s)
-                    t0 = time.perf_counter()
-                    if aligned:
-                        setup["import_fast"] = setup.get("import_fast", 0) + int(plan.import_aligned(got))
-                    else:
-                        plan.set_csr(*got)
-                    be.synchronize()
-                    setup["receive_ms"].append((time.perf_counter() - t0) * 1e3)
-            if hasattr(plan, "stat"):
-                setup["code_bytes"] += plan.stat("code_bytes")
-                setup["device_bytes"] += plan.stat("device_bytes")
-                # balance of the channel deal: barrier-weighted slowest / mean wave, and the worst block (x 1000; 0 for
-                # a plan restored from a persisted code object)
-                try:
-                    setup.setdefault("deal", []).append((s.name, plan.stat("deal_slowest_over_mean_x1000"), plan.stat("deal_worst_block_x1000"),
-                                                         plan.stat("code_bytes")))
-                except Exception:       # (an older build of the library under ESCOIN_LIB: tools/ab.sh)
-                    pass
-            bias = synth.bias_vector(s, 2000 + 31 * lid)
-            bias = torch.from_numpy(bias).to(be.device) if bias is not None else None
-            layers.append((s, plan, bias, si, lid))
+            entries.append([s, plan, si, lid])
             lid += 1
+    # ---- phase 2: the broadcast, layer by layer (one message per layer, like NCCL<Dtype>::Broadcast per blob,
+    # parallel.cpp:189-200).  What travels: the ALIGNED form (CSR + channel deal + unit table + code object, one blob:
+    # escoin_plan_export_aligned) where the plan has one -- a receiver then loads the code rank 0 generated
+    # (import_aligned) instead of generating its own from the CSR (set_csr: 5-125 ms per layer) --, the CSR alone
+    # otherwise (--broadcast csr, or a backend without code).  The blob stays on the device the collective filled.
+    received = []
+    aligned = getattr(args, "broadcast", "aligned") == "aligned" and hasattr(entries[0][1], "export_aligned")
+    if dist_on:
+        for s, plan, si, lid_ in entries:
+            mg = s.M // s.group
+            be.synchronize()
+            t0 = time.perf_counter()
+            if aligned:
+                got = pkg.shard.broadcast_blob(plan.export_aligned() if rank == 0 else None, src=0, device=be.device,
+                                               keep_on_device=not test_be(be))
+            else:
+                csr = plan.get_csr() if rank == 0 else None
+                got = pkg.shard.broadcast_csr(csr, s.group, s.group * (mg + 1), synth.nnz_of(s), src=0, device=be.device)
+            be.synchronize()
+            t_bcast += time.perf_counter() - t0
+            received.append(got)
+    # ---- phase 3: the receivers build their plans from what arrived -- on a few host threads: the C ABI is
+    # thread-compatible (one plan per thread at a time) and the code object loads of different plans overlap
+    # (tools/dbg/import_threads.py: three 11 MB imports side by side take as long as 1.2 of them)
+    if dist_on and (rank != 0 or loopback):
+        if loopback:
+            for e in entries:
+                e[1].close()
+                e[1] = be.make_plan(e[0])
+        per_layer = [0.0] * len(entries)
+        fast = [0] * len(entries)
+
+        def receive(k):
+            t1 = time.perf_counter()
+            if aligned:
+                fast[k] = int(entries[k][1].import_aligned(received[k]))
+            else:
+                entries[k][1].set_csr(*received[k])
+            per_layer[k] = (time.perf_counter() - t1) * 1e3
+        n_workers = max(1, min(int(getattr(args, "receive_threads", 4) or 1), len(entries)))
+        be.synchronize()
+        t0 = time.perf_counter()
+        if n_workers > 1 and not test_be(be):
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=n_workers) as ex:
+                list(ex.map(receive, range(len(entries))))
+        else:
+            for k in range(len(entries)):
+                receive(k)
+        be.synchronize()
+        setup["receive_wall_ms"] = (time.perf_counter() - t0) * 1e3
+        setup["receive_threads"] = n_workers
+        setup["receive_ms"] = per_layer
+        if aligned:
+            setup["import_fast"] = sum(fast)
+    del received
+    for s, plan, si, lid_ in entries:
+        if hasattr(plan, "stat"):
+            setup["code_bytes"] += plan.stat("code_bytes")
+            setup["device_bytes"] += plan.stat("device_bytes")
+            # balance of the channel deal: barrier-weighted slowest / mean wave, and the worst block (x 1000; 0 for
+            # a plan restored from a persisted code object)
+            try:
+                setup.setdefault("deal", []).append((s.name, plan.stat("deal_slowest_over_mean_x1000"), plan.stat("deal_worst_block_x1000"),
+                                                     plan.stat("code_bytes")))
+            except Exception:       # (an older build of the library under ESCOIN_LIB: tools/ab.sh)
+                pass
+        bias = synth.bias_vector(s, 2000 + 31 * lid_)
+        bias = torch.from_numpy(bias).to(be.device) if bias is not None else None
+        layers.append((s, plan, bias, si, lid_))
     return layers, t_bcast, setup
 
 
@@ -769,10 +801,14 @@ def run(args, be, pkg, synth, oracle_loader, dist=None):
     if dist_on:
         # the slowest receiver's set_csr total and its slowest layer (rank 0 has none: it aligned -- unless it is its
         # own receiver, --force-dist on one rank)
-        t = torch.tensor([sum(setup["receive_ms"]), max(setup["receive_ms"] or [0.0]), -float(setup.get("import_fast", 0)) if (rank or world == 1) else -1e9],
+        t = torch.tensor([setup.get("receive_wall_ms", 0.0), max(setup["receive_ms"] or [0.0]), -float(setup.get("import_fast", 0)) if (rank or world == 1) else -1e9,
+                          sum(setup["receive_ms"])],
                          device=be.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # total = wall time of the slowest receiver from "every layer's message is here" to "every plan is ready"
+        # (its layers are imported on `threads` host threads); sum_per_layer = the same work added up layer by layer
         receive = {"total": round(float(t[0].item()), 2), "max_per_layer": round(float(t[1].item()), 2),
+                   "sum_per_layer": round(float(t[3].item()), 2), "threads": setup.get("receive_threads", 1),
                    "what": getattr(args, "broadcast", "aligned"),
                    # layers whose persisted code object every receiver loaded as it was (the fewest over the receivers)
                    "code_objects_loaded_as_sent": int(-t[2].item()) if t[2].item() > -1e8 else 0}
@@ -1000,6 +1036,9 @@ def parse_args(argv=None):
     ap.add_argument("--broadcast", default="aligned", choices=["aligned", "csr"],
                     help="N > 1: what rank 0 broadcasts per layer -- the aligned form incl. the generated code (receivers "
                          "load it as it is), or the CSR alone (receivers run their own WeightAlign tail)")
+    ap.add_argument("--receive-threads", type=int, default=4,
+                    help="N > 1: host threads a receiver imports its layers on (the code object loads of different plans "
+                         "overlap; 1 = layer by layer)")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue the step's (independent) layers round robin on this many HIP streams; 1 = one stream, as "
                          "the reference launches its layers (the default and the judged line)")

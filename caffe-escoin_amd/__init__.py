@@ -31,7 +31,7 @@ API_SYMBOLS = [
     "escoin_plan_create", "escoin_plan_destroy", "escoin_plan_set_option",
     "escoin_weight_align", "escoin_plan_set_csr", "escoin_plan_nnz", "escoin_plan_get_csr",
     "escoin_plan_workspace_bytes", "escoin_plan_kernel_name", "escoin_plan_tiling_info", "escoin_forward",
-    "escoin_plan_export_aligned", "escoin_plan_import_aligned", "escoin_plan_stat",
+    "escoin_plan_export_aligned", "escoin_plan_import_aligned", "escoin_plan_import_aligned_dev", "escoin_plan_stat",
     "escoin_gpu_sconv", "escoin_gpu_stretch", "escoin_copy_input_data",
     "escoin_gpu_sparse_dense2csr", "escoin_gpu_sparse_csrmm",
     # Dtype = double
@@ -118,6 +118,8 @@ def lib():
     L.escoin_plan_export_aligned.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.escoin_plan_import_aligned.restype = ip
     L.escoin_plan_import_aligned.argtypes = [vp, vp, C.c_size_t, vp]
+    L.escoin_plan_import_aligned_dev.restype = ip
+    L.escoin_plan_import_aligned_dev.argtypes = [vp, vp, C.c_size_t, vp]
     L.escoin_plan_stat.restype = C.c_long
     L.escoin_plan_stat.argtypes = [vp, cp]
     L.escoin_gpu_sconv.restype = ip
@@ -291,7 +293,15 @@ class Plan(object):
         return buf[:n.value]
 
     def import_aligned(self, blob, stream=None):
-        """Restore what export_aligned wrote; True when the persisted code object was loaded as it was."""
+        """Restore what export_aligned wrote; True when the persisted code object was loaded as it was.
+        blob: numpy uint8 (host), or a torch CUDA uint8 tensor -- the buffer an RCCL broadcast filled -- which is
+        handed over as it is (escoin_plan_import_aligned_dev: no .cpu().numpy() round trip)."""
+        if not isinstance(blob, np.ndarray) and getattr(blob, "is_cuda", False):
+            t = blob.contiguous()
+            assert t.element_size() == 1
+            check(lib().escoin_plan_import_aligned_dev(self._h, C.c_void_p(t.data_ptr()), t.numel(), stream),
+                  "escoin_plan_import_aligned_dev")
+            return self.stat("import_fast") == 1
         b = np.ascontiguousarray(blob, np.uint8)
         check(lib().escoin_plan_import_aligned(self._h, _np_ptr(b), b.size, stream), "escoin_plan_import_aligned")
         return self.stat("import_fast") == 1

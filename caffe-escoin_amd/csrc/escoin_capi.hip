@@ -96,6 +96,49 @@ static void free_device(escoin_plan *p) {
   p->device_bytes = 0;
 }
 
+// Small launches.  The LDS-tiled kernels walk a tile block by block, every block a round trip to HBM, on as many
+// workgroups as the batch has tiles x columns: 11-19 us for one image of a GoogLeNet 1x1 layer; the generic kernel
+// puts a lane on every output pixel of the whole chip and needs 7-12 (profiles/r04_batch_sweep.md -- the reference's
+// SCONV mode calls the layer image by image, conv_layer.cu:16-26).  Round 4 TIMED both kernels; a layer's bits then
+// depended on the box's noise (two ranks could settle differently).  Now a RULE decides, from what WeightAlign knows --
+// the same weights, options and batch give the same kernel in every process on the same device model:
+//   pointwise layers only (the 3x3 / 5x5 layers keep generated code at every batch: the generic kernel needs
+//   16-81 us where code needs 12-16), a launch of one round (tiles x columns <= workgroup slots of the chip: CUs, or
+//   2 x CUs for the half-workgroup tilings) under 64 MFLOP;
+//   generic  ~ max(7.0, 5.8 + 0.125 r, 6.2 + waves x (0.143 + 0.0473 r) / 1000)   us; r = nonzeros per output row (the
+//              CSR row a wave walks with scalar loads: a latency chain), waves = N x M x ceil(OH OW / 64)
+//   code     ~ 7.6 + (0.6 chained | 1.1 one call per block) x blocks per tile + 0.1 x MB of blobs    us
+//   the kernel with the lower estimate.
+// Fitted to 180 cells (profiles/r05_small_launch_fit.md; tools/small_launch_fit.py: both kernels forced, 1-32 images
+// of every distinct GoogLeNet 1x1 shape): the models are within 6 % (code) / 12 % (generic) rms of the measurements
+// and the rule's pick is at most 12.7 % behind the faster kernel, two cells of 180 more than 10 %.
+// Evaluated from the TILING, before any code is generated or loaded (round 6): a layer the rule sends to
+// the generic kernel no longer pays for code generation and a module load / unload at every WeightAlign.
+// Returns 0 (not considered), 1 (generated code), 2 (generic kernel).
+int small_launch_rule(const escoin_plan *p, const Tiling &t, bool chained) {
+  const Geometry &g = p->g;
+  if (!(p->kernel_choice == ESCOIN_KERNEL_AUTO && p->n_dense_groups == 0 && (p->tiling_batch <= 0 || p->tiling_batch == g.d.N) &&
+        g.d.KH == 1 && g.d.KW == 1))
+    return 0;
+  long nnz = 0;
+  for (const auto &c : p->colidx) nnz += (long)c.size();
+  const double flops = 2.0 * g.d.N * g.OH * g.OW * (double)nnz;
+  const long tiles = t.band_mode ? (long)g.d.N * t.bands : ((long)g.d.N + t.nseg - 1) / t.nseg;
+  const long wgs = tiles * t.n_ocblk * g.d.group;
+  const long slots = (long)tiled_device_cus() * (t.waves == 4 ? 2 : 1);
+  if (!(flops < 64e6 && wgs <= slots)) return 0;
+  const double r = (double)nnz / (double)g.d.M;
+  const double waves = (double)g.d.N * g.d.M * std::ceil((double)g.OH * g.OW / 64.0);
+  const double mb = 4.0 * g.d.N * ((double)g.d.C * g.d.H * g.d.W + (double)g.d.M * g.OH * g.OW) * 1e-6;
+  const double t_gen = std::max(std::max(7.0, 5.8 + 0.125 * r), 6.2 + waves * (0.143 + 0.0473 * r) * 1e-3);
+  const double t_code = 7.6 + (chained ? 0.6 : 1.1) * t.n_icb + 0.1 * mb;
+  const int pick = t_gen < t_code ? 2 : 1;
+  if (getenv("ESCOIN_VERBOSE"))
+    fprintf(stderr, "[escoin] small launch (%.1f MFLOP, %ld workgroups on %ld slots, %d blocks): code ~%.1f us, generic ~%.1f us -> %s\n",
+            flops * 1e-6, wgs, slots, t.n_icb, t_code, t_gen, pick == 2 ? "generic" : "code");
+  return pick;
+}
+
 // Dtype = double: rowptr / packed taps / double values for the order-preserving generic kernel -- the only device
 // kernel a double plan runs, in every conv_mode (fp64 vector FMA is native on gfx950; the LDS-tiled, generated-code and
 // MFMA kernels are fp32: north_star measures fp32, double is boundary completeness, conv_layer.cu:75).
@@ -272,6 +315,7 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
     p->aligned = true;
     return ESCOIN_OK;
   }
+  p->small_rule = 0;
   const bool explicit_tiled = p->kernel_choice == ESCOIN_KERNEL_TILED || p->kernel_choice == ESCOIN_KERNEL_JIT;
   const bool want_tiled = explicit_tiled || (p->kernel_choice == ESCOIN_KERNEL_AUTO && tiled_supported(g));
   if (want_tiled) {
@@ -299,12 +343,13 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
                          (p->kernel_choice == ESCOIN_KERNEL_AUTO && jit_available() && sparse_enough);
     int rc = ESCOIN_OK;
     p->import_fast = false;
+    p->small_rule = 0;     // (set by tiled_build / tiled_import from the tiling, before any code is generated or loaded)
     if (try_jit && jit_blob && jit_blob_bytes > 0) {
       rc = tiled_import(p, jit_blob, jit_blob_bytes, stream);     // (leaves tiled.enabled false when the blob does not fit)
       if (rc != ESCOIN_OK) return rc;
       p->import_fast = p->tiled.enabled;
     }
-    if (try_jit && !p->tiled.enabled) {
+    if (try_jit && !p->tiled.enabled && p->small_rule != 2) {
       rc = tiled_build(p, stream, true);
       if (rc != ESCOIN_OK && p->kernel_choice == ESCOIN_KERNEL_JIT) return rc;
       if (!p->tiled.enabled && p->kernel_choice == ESCOIN_KERNEL_JIT)
@@ -322,51 +367,12 @@ static int upload(escoin_plan *p, hipStream_t stream, const char *jit_blob = nul
         rc = ESCOIN_OK;
       }
     }
-    if (!p->tiled.enabled) {
+    if (!p->tiled.enabled && p->small_rule != 2) {
       rc = tiled_build(p, stream, false);   // leaves tiled.enabled false when the stream does not fit LDS
       if (rc != ESCOIN_OK) return rc;
     }
     if (!p->tiled.enabled && p->kernel_choice == ESCOIN_KERNEL_TILED)
       return fail(ESCOIN_EINVAL, "tiled kernel requested but its weight stream does not fit the LDS budget");
-  }
-  // Small launches.  The LDS-tiled kernels walk a tile block by block, every block a round trip to HBM, on as many
-  // workgroups as the batch has tiles x columns: 11-19 us for one image of a GoogLeNet 1x1 layer; the generic kernel
-  // puts a lane on every output pixel of the whole chip and needs 7-12 (profiles/r04_batch_sweep.md -- the reference's
-  // SCONV mode calls the layer image by image, conv_layer.cu:16-26).  Round 4 TIMED both kernels here; a layer's bits
-  // then depended on the box's noise (two ranks could settle differently).  Now a RULE decides, from what WeightAlign
-  // knows -- the same weights, options and batch give the same kernel in every process:
-  //   pointwise layers only (the 3x3 / 5x5 layers keep generated code at every batch: the generic kernel needs
-  //   16-81 us where code needs 12-16), a launch of one round (tiles x columns <= CUs) under 64 MFLOP;
-  //   generic  ~ max(7.0, 5.8 + 0.125 r, 6.2 + waves x (0.143 + 0.0473 r) / 1000)   us; r = nonzeros per output row (the
-  //              CSR row a wave walks with scalar loads: a latency chain), waves = N x M x ceil(OH OW / 64)
-  //   code     ~ 7.6 + (0.6 chained | 1.1 one call per block) x blocks per tile + 0.1 x MB of blobs    us
-  //   the kernel with the lower estimate.
-  // Fitted to 180 cells (profiles/r05_small_launch_fit.md; tools/small_launch_fit.py: both kernels forced, 1-32 images
-  // of every distinct GoogLeNet 1x1 shape): the models are within 6 % (code) / 12 % (generic) rms of the measurements
-  // and the rule's pick is at most 12.7 % behind the faster kernel, two cells of 180 more than 10 %.
-  p->small_rule = 0;
-  if (p->kernel_choice == ESCOIN_KERNEL_AUTO && p->tiled.enabled && p->n_dense_groups == 0 &&
-      (p->tiling_batch <= 0 || p->tiling_batch == g.d.N) && g.d.KH == 1 && g.d.KW == 1) {
-    const double flops = 2.0 * g.d.N * g.OH * g.OW * (double)nnz;
-    const Tiling &t = p->tiled.tiling;
-    const long tiles = t.band_mode ? (long)g.d.N * t.bands : ((long)g.d.N + t.nseg - 1) / t.nseg;
-    const long wgs = tiles * t.n_ocblk * G;
-    if (flops < 64e6 && wgs <= tiled_device_cus()) {
-      const double r = (double)nnz / (double)g.d.M;
-      const double waves = (double)g.d.N * g.d.M * std::ceil((double)g.OH * g.OW / 64.0);
-      const double mb = 4.0 * g.d.N * ((double)g.d.C * g.d.H * g.d.W + (double)g.d.M * g.OH * g.OW) * 1e-6;
-      const double t_gen = std::max(std::max(7.0, 5.8 + 0.125 * r), 6.2 + waves * (0.143 + 0.0473 * r) * 1e-3);
-      const double t_code = 7.6 + (p->tiled.jit_chain ? 0.6 : 1.1) * t.n_icb + 0.1 * mb;
-      p->small_rule = t_gen < t_code ? 2 : 1;
-      if (getenv("ESCOIN_VERBOSE"))
-        fprintf(stderr, "[escoin] small launch (%.1f MFLOP, %ld workgroups, %d blocks): code ~%.1f us, generic ~%.1f us -> %s\n",
-                flops * 1e-6, wgs, t.n_icb, t_code, t_gen, p->small_rule == 2 ? "generic" : "code");
-      if (p->small_rule == 2) {
-        const float d0 = p->tiled.density;
-        tiled_release(p);
-        p->tiled.density = d0;
-      }
-    }
   }
   p->kernel_name = p->tiled.enabled ? tiled_kernel_name(p) : generic_kernel_name(g.d.fuse_relu != 0);
   if (p->n_dense_groups > 0) p->kernel_name += std::string(" + ") + dense_kernel_name();
@@ -664,10 +670,40 @@ extern "C" {
 // [AlignedHdr][desc][nnz_per_group][rowptr][colidx][values][generated-code section (sconv_tiled.hip)]
 namespace {
 constexpr uint32_t kAlignedMagic = 0x4E474C41u;   // "ALGN"
+constexpr uint32_t kAlignedVersion = 2u;          // 2: content tags over the CSR and the code section (round 6)
 struct AlignedHdr {
   uint32_t magic, version;
   uint64_t total_bytes, nnz, jit_bytes;
+  // Content tags: 64-bit hashes of the CSR section (descriptor included) and of the generated-code section, and a
+  // third one binding the two -- the code was generated FROM this CSR.  A blob whose sections come from different
+  // exports (a torn or spliced broadcast, a stale cache file patched with new weights) is refused instead of running
+  // code that disagrees with its CSR.  Not a security boundary: an integrity check against accidents.
+  uint64_t csr_tag, jit_tag, pair_tag;
 };
+
+// 4 x 64-bit multiply-rotate lanes over 32-byte stripes (the shape of XXH64's main loop): ~10 GB/s on a host core, so
+// tagging the 54 MB of the 16 ResNet layers costs ~5 ms per side.
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+uint64_t content_tag(const void *data, size_t n, uint64_t seed) {
+  const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull;
+  const unsigned char *p = static_cast<const unsigned char *>(data);
+  uint64_t v[4] = {seed + P1 + P2, seed + P2, seed, seed - P1};
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32)
+    for (int k = 0; k < 4; ++k) {
+      uint64_t w;
+      memcpy(&w, p + i + 8 * k, 8);
+      v[k] = rotl64(v[k] + w * P2, 31) * P1;
+    }
+  uint64_t h = rotl64(v[0], 1) + rotl64(v[1], 7) + rotl64(v[2], 12) + rotl64(v[3], 18) + (uint64_t)n;
+  for (; i < n; ++i) h = rotl64(h ^ (p[i] * P3), 11) * P1;
+  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+  return h;
+}
+uint64_t pair_tag_of(uint64_t a, uint64_t b) {
+  const uint64_t both[2] = {a, b};
+  return content_tag(both, sizeof(both), 0x6573636F696E3236ull);
+}
 }  // namespace
 
 int escoin_plan_export_aligned(const escoin_plan *p, void *buf, size_t capacity, size_t *bytes) {
@@ -687,14 +723,20 @@ int escoin_plan_export_aligned(const escoin_plan *p, void *buf, size_t capacity,
     if (!buf) return ESCOIN_OK;                       // size query
     if (capacity < need) return fail(ESCOIN_EINVAL, "export_aligned: buffer too small");
     char *q = static_cast<char *>(buf);
-    AlignedHdr h{kAlignedMagic, 1u, (uint64_t)need, nnz, (uint64_t)jit.size()};
-    memcpy(q, &h, sizeof(h)); q += sizeof(h);
+    AlignedHdr h{kAlignedMagic, kAlignedVersion, (uint64_t)need, nnz, (uint64_t)jit.size(), 0, 0, 0};
+    char *const hdr_at = q;
+    q += sizeof(h);
+    const char *const csr_at = q;
     memcpy(q, &g.d, sizeof(g.d)); q += sizeof(g.d);
     for (int grp = 0; grp < g.d.group; ++grp) { const int n = (int)p->colidx[grp].size(); memcpy(q, &n, 4); q += 4; }
     for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->rowptr[grp].data(), 4 * (size_t)(g.Mg + 1)); q += 4 * (size_t)(g.Mg + 1); }
     for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->colidx[grp].data(), 4 * p->colidx[grp].size()); q += 4 * p->colidx[grp].size(); }
     for (int grp = 0; grp < g.d.group; ++grp) { memcpy(q, p->values[grp].data(), 4 * p->values[grp].size()); q += 4 * p->values[grp].size(); }
+    h.csr_tag = content_tag(csr_at, (size_t)(q - csr_at), 1);
     if (!jit.empty()) memcpy(q, jit.data(), jit.size());
+    h.jit_tag = content_tag(q, jit.size(), 2);
+    h.pair_tag = pair_tag_of(h.csr_tag, h.jit_tag);
+    memcpy(hdr_at, &h, sizeof(h));
     return ESCOIN_OK;
   });
 }
@@ -708,8 +750,8 @@ int escoin_plan_import_aligned(escoin_plan *p, const void *buf, size_t bytes, vo
     if (bytes < sizeof(h) + sizeof(escoin_conv_desc)) return fail(ESCOIN_EINVAL, "import_aligned: truncated blob");
     const char *q = static_cast<const char *>(buf);
     memcpy(&h, q, sizeof(h)); q += sizeof(h);
-    if (h.magic != kAlignedMagic || h.version != 1u || h.total_bytes != bytes)
-      return fail(ESCOIN_EINVAL, "import_aligned: not an aligned-form blob of this library");
+    if (h.magic != kAlignedMagic || h.version != kAlignedVersion || h.total_bytes != bytes)
+      return fail(ESCOIN_EINVAL, "import_aligned: not an aligned-form blob of this library build");
     escoin_conv_desc d;
     memcpy(&d, q, sizeof(d)); q += sizeof(d);
     // the weights' own geometry must match; batch, bias and ReLU are the importing plan's business
@@ -720,6 +762,15 @@ int escoin_plan_import_aligned(escoin_plan *p, const void *buf, size_t bytes, vo
       return fail(ESCOIN_EINVAL, "import_aligned: nnz or code section larger than the layer / the blob");
     const size_t csr_bytes = 4 * (size_t)g.d.group + 4 * (size_t)g.d.group * (g.Mg + 1) + 8 * (size_t)h.nnz;
     if (sizeof(h) + sizeof(d) + csr_bytes + h.jit_bytes != bytes) return fail(ESCOIN_EINVAL, "import_aligned: section sizes do not add up");
+    {
+      // the content tags, before a single byte of either section is trusted
+      const char *csr_at = static_cast<const char *>(buf) + sizeof(h);
+      const size_t csr_sec = sizeof(d) + csr_bytes;
+      const uint64_t ct = content_tag(csr_at, csr_sec, 1), jt = content_tag(csr_at + csr_sec, (size_t)h.jit_bytes, 2);
+      if (ct != h.csr_tag || jt != h.jit_tag || pair_tag_of(ct, jt) != h.pair_tag)
+        return fail(ESCOIN_EINVAL, "import_aligned: content tag mismatch -- the blob is torn, or its code section does not belong to its CSR section");
+    }
+    const double ms_tags = ms_since(t_start);
     std::vector<int> ng(g.d.group), rp((size_t)g.d.group * (g.Mg + 1)), ci((size_t)h.nnz);
     std::vector<float> va((size_t)h.nnz);
     memcpy(ng.data(), q, 4 * ng.size()); q += 4 * ng.size();
@@ -737,9 +788,34 @@ int escoin_plan_import_aligned(escoin_plan *p, const void *buf, size_t bytes, vo
     const bool same_geom = d.H == g.d.H && d.W == g.d.W && d.pad_h == g.d.pad_h && d.pad_w == g.d.pad_w &&
                            d.stride_h == g.d.stride_h && d.stride_w == g.d.stride_w && d.dil_h == g.d.dil_h &&
                            d.dil_w == g.d.dil_w && d.N == g.d.N;
+    const double ms_csr = ms_since(t_start);
     const int rc2 = upload(p, (hipStream_t)stream, same_geom && h.jit_bytes ? q : nullptr, same_geom ? (size_t)h.jit_bytes : 0);
     p->align_ms = ms_since(t_start);
+    if (getenv("ESCOIN_VERBOSE"))
+      fprintf(stderr, "[escoin] import_aligned: %zu bytes (code %llu): tags %.2f ms, CSR checks %.2f ms, upload + code load %.2f ms\n",
+              bytes, (unsigned long long)h.jit_bytes, ms_tags, ms_csr - ms_tags, p->align_ms - ms_csr);
     return rc2;
+  });
+}
+
+// The same from a DEVICE buffer (where an RCCL broadcast leaves the blob): one copy into a host staging area that the
+// calling thread keeps between calls (grow-only; pageable -- pinning 13 MB costs more than the copy saves), then the
+// host import: the CSR and the code object are parsed and loaded from host memory either way (hipModuleLoadData takes a
+// host image).
+namespace {
+thread_local std::vector<char> g_stage;
+}  // namespace
+
+int escoin_plan_import_aligned_dev(escoin_plan *p, const void *dev_buf, size_t bytes, void *stream) {
+  return guarded([&]() -> int {
+    if (!p || !dev_buf) return fail(ESCOIN_EINVAL, "null argument");
+    if (bytes < sizeof(AlignedHdr) || bytes > (size_t)1 << 36) return fail(ESCOIN_EINVAL, "import_aligned: implausible blob size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ESCOIN_ENODEVICE, "no HIP device");
+    if (g_stage.size() < bytes) g_stage.resize(bytes + (bytes >> 2));     // (grows by a quarter: layers come in rising sizes)
+    ESCOIN_HIP_TRY(hipMemcpyAsync(g_stage.data(), dev_buf, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ESCOIN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return escoin_plan_import_aligned(p, g_stage.data(), bytes, stream);
   });
 }
 

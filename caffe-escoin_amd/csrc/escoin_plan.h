@@ -198,6 +198,10 @@ int launch_tiled(const escoin_plan *p, const float *bottom, const float *bias, f
                  int n_images, hipStream_t stream);
 const char *tiled_kernel_name(const escoin_plan *p);
 
+// escoin_capi.hip: KERNEL_AUTO's rule for pointwise launches of one round of workgroups under 64 MFLOP, evaluated from
+// the tiling before any code is generated or loaded: 0 not considered, 1 generated code, 2 the generic kernel.
+int small_launch_rule(const escoin_plan *p, const Tiling &t, bool chained);
+
 // sconv_lowered.hip (conv_mode LOWERED_SPARSE: im2col + CSR x dense, the lowering baseline)
 int launch_lowered(escoin_plan *p, const float *bottom, const float *bias, float *top, int n_images,
                    hipStream_t stream);

@@ -7,7 +7,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
-#include <system_error>
+#include "parallel_for.h"
 #include <thread>
 
 namespace escoin {
@@ -469,25 +469,9 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
   for (const auto &c : colidx) nnz += c.size();
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const size_t n_thr = nnz >= 20000 && n_chains > 1 ? std::min<size_t>(std::min<size_t>(8, hw), n_chains) : 1;
-  if (n_thr <= 1) {
-    for (size_t ci = 0; ci < n_chains; ++ci) run(ci);
-  } else {
-    // (the calling thread works too; a thread the system refuses to create is simply one worker fewer)
-    std::vector<std::thread> pool;
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-      for (size_t i = next.fetch_add(1); i < n_chains; i = next.fetch_add(1)) run(i);
-    };
-    for (size_t th = 1; th < n_thr; ++th) {
-      try {
-        pool.emplace_back(worker);
-      } catch (const std::system_error &) {
-        break;
-      }
-    }
-    worker();
-    for (auto &th : pool) th.join();
-  }
+  // (parallel_for.h: the calling thread works too, a thread the system refuses is one worker fewer, an exception on
+  //  any thread -- a code vector that cannot grow -- is rethrown here after the helpers were joined)
+  parallel_for(n_chains, n_thr, run);
   size_t total = 0;
   for (const ChainOut &c : outs) total += c.code.size() + kUnitAlign / 4;
   p.code.reserve(total + 64 + (size_t)n_pref * 1024);

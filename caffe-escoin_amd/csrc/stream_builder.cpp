@@ -6,7 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
-#include <system_error>
+#include "parallel_for.h"
 #include <thread>
 #include <cstdlib>
 #include <cstring>
@@ -454,25 +454,9 @@ std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const
   const size_t work = (size_t)Mg * nb * words;
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const size_t n_thr = work >= 4096 && cols.size() > 1 ? std::min<size_t>(std::min<size_t>(8, hw), cols.size()) : 1;
-  if (n_thr <= 1) {
-    for (int blk0 : cols) deal_column(blk0);
-  } else {
-    // (the calling thread works too; a thread the system refuses to create is simply one worker fewer)
-    std::vector<std::thread> pool;
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-      for (size_t i = next.fetch_add(1); i < cols.size(); i = next.fetch_add(1)) deal_column(cols[i]);
-    };
-    for (size_t th = 1; th < n_thr; ++th) {
-      try {
-        pool.emplace_back(worker);
-      } catch (const std::system_error &) {
-        break;
-      }
-    }
-    worker();
-    for (auto &th : pool) th.join();
-  }
+  // (parallel_for.h: the calling thread works too, a thread the system refuses is one worker fewer, an exception on
+  //  any thread is rethrown here after the helpers were joined)
+  parallel_for(cols.size(), n_thr, [&](size_t i) { deal_column(cols[i]); });
   // slots past the last channel of a partly filled oc-group repeat a valid channel
   return slot;
 }

@@ -60,10 +60,12 @@ def broadcast_csr(csr, n_groups, n_rowptr, nnz, src=0, device="cpu", group=None)
     return unpack_csr(t.cpu().numpy())
 
 
-def broadcast_blob(blob, src=0, device="cpu", group=None):
+def broadcast_blob(blob, src=0, device="cpu", group=None, keep_on_device=False):
     """Broadcast a byte blob (numpy uint8 on the source rank, ignored elsewhere) whose size only the source
     knows: the aligned form of a layer (escoin_plan_export_aligned: CSR + channel deal + unit table + code
-    object), so that receivers load the code rank 0 generated instead of generating their own."""
+    object), so that receivers load the code rank 0 generated instead of generating their own.
+    keep_on_device: return the tensor the collective filled (a CUDA tensor under RCCL) -- Plan.import_aligned takes
+    it as it is; otherwise a numpy copy."""
     import torch
     import torch.distributed as dist
     is_src = dist.get_rank(group) == src
@@ -74,4 +76,6 @@ def broadcast_blob(blob, src=0, device="cpu", group=None):
     else:
         t = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
     dist.broadcast(t, src=src, group=group)
+    if keep_on_device and t.is_cuda:
+        return t
     return t.cpu().numpy()

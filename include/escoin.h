@@ -189,17 +189,25 @@ ESCOIN_API size_t escoin_plan_workspace_bytes(const escoin_plan *plan);
  *           (escoin_plan_stat(plan, "import_fast") == 1); otherwise it aligns from the CSR like
  *           escoin_plan_set_csr -- also when the device refuses the persisted code object.  Plan options must be
  *           set before the import, as before weight_align.  Every field of the blob is range-checked before it
- *           sizes or indexes anything; a malformed blob gives ESCOIN_EINVAL, never a crash. */
+ *           sizes or indexes anything; a malformed blob gives ESCOIN_EINVAL, never a crash.  The header carries 64-bit
+ *           content tags of the CSR section and of the code section and one binding the two: a blob whose code does not
+ *           belong to its CSR (a torn broadcast, a spliced cache file) is refused with ESCOIN_EINVAL -- it can never
+ *           run stale code on new weights.  (An integrity check against accidents, not a security boundary.) */
 ESCOIN_API int escoin_plan_export_aligned(const escoin_plan *plan, void *buf, size_t capacity, size_t *bytes);
 ESCOIN_API int escoin_plan_import_aligned(escoin_plan *plan, const void *buf, size_t bytes, void *stream);
+/* The same from a DEVICE buffer -- where an RCCL broadcast leaves the blob (NCCL<Dtype>::Broadcast, parallel.cpp:189-200):
+ * one copy into a pinned staging area the calling thread keeps between calls, then the import above. */
+ESCOIN_API int escoin_plan_import_aligned_dev(escoin_plan *plan, const void *dev_buf, size_t bytes, void *stream);
 
 /* Integer facts about an aligned plan (negative = error): "align_us" wall time of the last
  * weight_align / set_csr / import_aligned, "code_bytes" generated machine code on the device,
  * "device_bytes", "import_fast", "jit_rows", "jit_records", "lds_bytes", "workgroup_columns",
  * "kernel_choice" (the ESCOIN_KERNEL_* id AUTO resolved to for the sparse groups), "small_launch_rule" (KERNEL_AUTO's
  * rule for pointwise launches under 64 MFLOP that fit one round of workgroups -- the reference's SCONV mode runs
- * image by image, conv_layer.cu:16-26 --: 0 not considered, 1 kept generated code, 2 took the generic kernel; a
- * function of the options, the weights and the batch only: the same in every process),
+ * image by image, conv_layer.cu:16-26 --: 0 not considered, 1 kept generated code, 2 took the generic kernel (decided
+ * from the tiling before any code is generated or loaded); a function of the options, the weights, the batch and the
+ * device MODEL -- its CU count and whether generated code is available -- never of a timing: the same in every process
+ * on the same kind of device),
  * "deal_slowest_over_mean_x1000" / "deal_worst_block_x1000" (generated-code plans aligned from weights: how evenly
  * WeightAlign dealt the output channels over the waves that meet at a block's barrier -- slowest wave / mean wave,
  * weighted over all blocks, and the worst single block, x 1000; 0 for a plan restored from a persisted code object),

@@ -183,7 +183,38 @@ def test_export_import_aligned_round_trip(pkg, oracle, synth):
                        (np.concatenate([blob[:1] ^ 0xFF, blob[1:]]), pkg.Plan(pkg.ConvDesc.from_shape(s)))):
             with pytest.raises(pkg.EscoinError):
                 p.import_aligned(bad)
-        for q in (plan, p2, p3, other):
+        # (4) the content tags (round 6): one flipped byte in the code section, one in the CSR values, and a blob spliced
+        # from the CSR of one export and the code of another (same sizes, other weights, each section's own tag intact)
+        # -- all refused: a receiver can never run code that was not generated from the CSR it carries
+        import struct
+        plan_b = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256)
+        wb = w.copy()
+        wb.reshape(-1)[np.flatnonzero(wb)] *= np.float32(1.5)    # same pattern, other values: same section sizes
+        plan_b.weight_align(wb)
+        blob_b = plan_b.export_aligned()
+        magic, version, total, nnz, jit_bytes, csr_tag, jit_tag, pair_tag = struct.unpack_from("<IIQQQQQQ", blob.tobytes())
+        assert total == blob.size and jit_bytes > 0 and version == 2
+        jit_at = total - jit_bytes
+        tampered = [blob.copy(), blob.copy()]
+        tampered[0][jit_at + jit_bytes // 2] ^= 0x01             # inside the code object
+        tampered[1][jit_at - 4 * nnz + 2] ^= 0x40                # inside the CSR values
+        tb = struct.unpack_from("<IIQQQQQQ", blob_b.tobytes())
+        if blob_b.size == blob.size and tb[4] == jit_bytes:
+            spliced = blob.copy()
+            spliced[jit_at:] = blob_b[jit_at:]                   # A's CSR, B's code ...
+            spliced[40:48] = blob_b[40:48]                       # ... with B's (valid) code tag; the pair tag is still A's
+            tampered.append(spliced)
+        for bad in tampered:
+            q = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256)
+            with pytest.raises(pkg.EscoinError) as e:
+                q.import_aligned(bad)
+            assert "content tag" in str(e.value)
+            q.close()
+        # the device-buffer import (what an RCCL broadcast hands over): same result as the host import
+        p4 = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256)
+        assert p4.import_aligned(torch.from_numpy(blob).to(dev)) is True
+        assert np.array_equal(p4.forward(x, bd).cpu().numpy(), want), s.name
+        for q in (plan, p2, p3, p4, other, plan_b):
             q.close()
     g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, group=s.group)
     ref = oracle.conv_forward(g, x.cpu().numpy(), w, b, gate=False)
