@@ -154,9 +154,14 @@ Tiling tile_for(const ConvGeom &g, int waves_per_wg, int lds_budget_bytes, int n
   };
   // (experiments flavour: ESCOIN_FORCE_PASSES / ESCOIN_FORCE_NSEG pin the workgroup columns per conv group / the images per
   //  tile, for sweeps of what the cost model could have chosen: tools/tiling_oracle.py)
-  if (ESC_KNOB_SET("FORCE_PASSES") || ESC_KNOB_SET("FORCE_NSEG")) {
-    const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, (int)ESC_KNOB("FORCE_PASSES", 0), (int)ESC_KNOB("FORCE_NSEG", 0));
-    if (t.ok && t.G >= 1) return t;
+  if (ESC_KNOB_SET("FORCE_PASSES") || ESC_KNOB_SET("FORCE_NSEG") || ESC_KNOB_SET("FORCE_TPL")) {
+    // (ESCOIN_FORCE_TPL=1: one quad per lane, up to 48 channels per wave -- generated code on pointwise layers whose tile
+    //  rows fit tile A, the same conditions as the search below)
+    const int tpl = (int)ESC_KNOB("FORCE_TPL", kTilesPerLane);
+    const Tiling t = tile_with(g, waves_per_wg, lds_budget_bytes, (int)ESC_KNOB("FORCE_PASSES", 0), (int)ESC_KNOB("FORCE_NSEG", 0), tpl);
+    const bool tpl_ok = tpl == kTilesPerLane || (tpl == 1 && one_tile_ok && g.KH == 1 && g.KW == 1 && !t.band_mode && t.pix_waves == 1 &&
+                                                 t.tr * t.nseg <= t.rows_per_slab);
+    if (t.ok && t.G >= 1 && tpl_ok) return t;
   }
   double best_cost = cost_of(best);
   const int base_passes = best.n_ocblk;

@@ -27,6 +27,11 @@ done
 for s in stream_builder jit_codegen jit_module; do
   /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -fvisibility=hidden -I. -I../../include $DEF ${ABL_CFLAGS:-} -c -o $O/$s.o $s.cpp & pids+=($!)
 done
+# Caffe::CPU mode: plain host translation units (the same flags as the product Makefile)
+CPUF="-x c++ -O3 -std=c++17 -fPIC -fvisibility=hidden -DESCOIN_BUILD -ffp-contract=off -I. -I../../include"
+/opt/rocm/bin/hipcc $CPUF -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $DEF -c -o $O/sconv_cpu.o sconv_cpu.cpp & pids+=($!)
+/opt/rocm/bin/hipcc $CPUF -DESC_CPU_ISA=2 -mavx2 -mfma -c -o $O/sconv_cpu_kernel_avx2.o sconv_cpu_kernel.cpp & pids+=($!)
+/opt/rocm/bin/hipcc $CPUF -DESC_CPU_ISA=512 -mavx512f -mavx512vl -mavx512dq -mavx2 -mfma -c -o $O/sconv_cpu_kernel_avx512.o sconv_cpu_kernel.cpp & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done     # a failed compile aborts the script (set -e)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libescoin_$TAG.so $O/*.o -lamd_comgr
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libescoin_$TAG.so $O/*.o -lamd_comgr -lpthread
 ls -la ../../tools/ab/libescoin_$TAG.so

@@ -58,15 +58,19 @@ def main():
         print("%s N=%d AUTO: %.1f us  columns=%s nseg=%s G=%s" % (name, n, us0 or -1, m.get("columns"), m.get("nseg"), m.get("G")), flush=True)
         seen = set()
         base = m.get("columns", 1)
-        for passes in sorted(set([1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, base])):
-            for nseg in (0, 1):
-                us, info = run(name, n, {"ESCOIN_FORCE_PASSES": str(passes), "ESCOIN_FORCE_NSEG": str(nseg)})
-                mm = {k: int(v) for k, v in re.findall(r"\b(columns|nseg|G|n_icb)=(\d+)", info)}
-                key = (mm.get("columns"), mm.get("nseg"), mm.get("G"))
+        nsegs = [int(v) for v in os.environ.get("ORACLE_NSEGS", "0,1").split(",")]
+        tpls = [int(v) for v in os.environ.get("ORACLE_TPLS", "2").split(",")]       # 1 = one quad per lane (pointwise layers)
+        pass_list = [int(v) for v in os.environ.get("ORACLE_PASSES", "1,2,3,4,5,6,7,8,10,12,16").split(",")]
+        for passes in sorted(set(pass_list + [base])):
+          for tpl in tpls:
+            for nseg in nsegs:
+                us, info = run(name, n, {"ESCOIN_FORCE_PASSES": str(passes), "ESCOIN_FORCE_NSEG": str(nseg), "ESCOIN_FORCE_TPL": str(tpl)})
+                mm = {k: int(v) for k, v in re.findall(r"\b(columns|nseg|G|n_icb|tpl)=(\d+)", info)}
+                key = (mm.get("columns"), mm.get("nseg"), mm.get("G"), mm.get("tpl"))
                 if us is None or key in seen:
                     continue
                 seen.add(key)
-                print("    columns=%s nseg=%s G=%s blocks=%s: %.1f us%s" % (key[0], key[1], key[2], mm.get("n_icb"), us, "  <-- better than AUTO by %.0f %%" % (100 * (1 - us / us0)) if us0 and us < 0.97 * us0 else ""), flush=True)
+                print("    columns=%s nseg=%s G=%s tpl=%s blocks=%s: %.1f us%s" % (key[0], key[1], key[2], key[3], mm.get("n_icb"), us, "  <-- better than AUTO by %.0f %%" % (100 * (1 - us / us0)) if us0 and us < 0.97 * us0 else ""), flush=True)
 
 
 if __name__ == "__main__":
