@@ -37,8 +37,29 @@
 
 #ifdef ESCOIN_ABLATIONS
 #define ESC_DENSE_ABL(a, bits) ((a).abl & (bits))
+// In-kernel stamp profile (ESCOIN_PROF=1 on the ablation flavour; round 6, profiles/r06_dense_stamps.md): shader cycles of
+// every wave by phase, summed over its tiles and k-steps --
+//   0 start-up (arguments, first tile's addressing, first fetch)    1 k-step top: wait for this wave's operand pieces
+//   2 k-step top: workgroup barrier                                 3 issuing the next k-step's fetch (LDS-DMA / gather)
+//   4 fragment reads + MFMAs                                        5 between tiles: coordinates, accumulator reset
+//   6 epilogue: bias, transpose through LDS, stores                 7 stream-K hand-over / fix-up
+#define ESC_DPROF_DECL unsigned long long dpt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpl_ = __builtin_readcyclecounter(); \
+  const unsigned long long dpc0_ = dpl_, dpr0_ = __builtin_amdgcn_s_memrealtime();
+#define ESC_DPROF(i) do { if (a.prof) { const unsigned long long n_ = __builtin_readcyclecounter(); dpt_[i] += n_ - dpl_; dpl_ = n_; } } while (0)
+#define ESC_DPROF_DUMP                                                                                              \
+  if (a.prof && (threadIdx.x & 63) == 0) {                                                                          \
+    for (int i_ = 0; i_ < 8; ++i_) a.prof[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = dpt_[i_];       \
+    if (threadIdx.x == 0) {                                                                                         \
+      a.prof[(size_t)32 * 4096 + 4 * (size_t)blockIdx.x] = __builtin_readcyclecounter() - dpc0_;                    \
+      a.prof[(size_t)32 * 4096 + 4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - dpr0_;            \
+      a.prof[(size_t)32 * 4096 + 4 * (size_t)blockIdx.x + 2] = dpr0_;                                               \
+    }                                                                                                               \
+  }
 #else
 #define ESC_DENSE_ABL(a, bits) (0)
+#define ESC_DPROF_DECL
+#define ESC_DPROF(i)
+#define ESC_DPROF_DUMP
 #endif
 
 namespace escoin {
@@ -63,6 +84,8 @@ struct DenseArgs {
   int s2_pair;                             // BMODE 2: a lane's two outputs come out of one aligned 16-byte quad (stride 2, even OW)
   unsigned long long group_mask;           // conv groups this launch covers (all ones: every group)
   int abl;                                 // ESCOIN_ABLATIONS builds: timing experiments (wrong results)
+  unsigned long long *prof;                // ESCOIN_ABLATIONS builds: stamp profile [workgroup][wave][8] (ESC_DPROF)
+  int fetch_slots;                         // the next k-step's LDS-DMA pieces go out between this k-step's MFMAs (1) or as a burst at its top (0)
   // stream-K (STREAMK instantiations): every workgroup takes an equal, contiguous run of (tile, k-step) units;
   // a tile cut by a run boundary is finished by the workgroup holding its last k-steps, which adds the others'
   // partial accumulators from `sk_ws` ([workgroup][wave][16 quads][64 lanes] floats x 4) once their `sk_flag`
@@ -128,6 +151,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
   __shared__ __attribute__((aligned(1024))) float sAB[2][kBufFloats];
   auto sA = [&](int b) -> float * { return &sAB[b][0]; };
   auto sB = [&](int b) -> float * { return &sAB[b][BM * kBK]; };
+  ESC_DPROF_DECL
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,6 +282,51 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
     }
   };
 
+  // The same fetch cut into 16 SLOTS, one per group of MFMAs of a k-step (kg, t): issued between the MFMAs, an LDS-DMA
+  // instruction costs its wave ~60 cycles under the shadow of the matrix instructions already queued; issued as one burst
+  // at the k-step's top (what `fetch` does, and what every k-step did until round 6) each holds the wave 100-270 cycles
+  // with the matrix pipe draining -- 15 % (K = 64 layers) to 48 % (stride-2 gather: 20 instructions per wave and k-step)
+  // of a wave's life by the stamp profile (profiles/r06_dense_stamps.md).  Pieces go out in the FIRST slots (two per
+  // slot for the gather, one otherwise) so that they have most of a k-step to land before the next top's wait.
+  int4 gt[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};      // gathered B: this wave's 8 taps of the k-step being fetched
+  auto fetch_slot = [&](int kstep, int buf, int slot) {
+    const int k0 = kstep * kBK;
+    if (slot < A_DMA) {
+      const unsigned sa = (unsigned)((((size_t)f_cg * a.Mg + f_m0) * a.lda + k0) * 4);
+      const int i = wave + 4 * slot;
+      dma16(rA, ldsA + (unsigned)buf * kBufBytes + (unsigned)(i * 1024), voffA, sa + (unsigned)(i * 8 * a.lda * 4));
+    }
+    if (POINTWISE4) {
+      if (slot >= 4 && slot < 8) {
+        const int i = wave + 4 * (slot - 4);
+        const unsigned vo = (k0 + 2 * i + (lane >> 5) < a.K) ? fb_pix[0] : kOOB;
+        dma16(rB, ldsB + (unsigned)buf * kBufBytes + (unsigned)(i * 1024), vo, (unsigned)((size_t)(k0 + 2 * i) * hw * 4));
+      }
+    } else if (!STRIDED1) {
+      if (slot == 0) {
+        const int4 *tp = reinterpret_cast<const int4 *>(a.ktab + k0 + 8 * wave);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {      // (wave-uniform: scalar registers, not four vector quads kept across eight slots)
+          const int4 v = tp[q];
+          gt[q].x = __builtin_amdgcn_readfirstlane(v.x); gt[q].y = __builtin_amdgcn_readfirstlane(v.y);
+          gt[q].z = __builtin_amdgcn_readfirstlane(v.z); gt[q].w = __builtin_amdgcn_readfirstlane(v.w);
+        }
+      }
+      if (slot < 8) {            // tap kk = slot: both halves
+        const int kk = slot;
+        const int toff = (kk & 1) ? gt[kk >> 1].z : gt[kk >> 1].x;
+        const int tdyx = (kk & 1) ? gt[kk >> 1].w : gt[kk >> 1].y;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int ih = fb_ih0[half] + (tdyx & 0xFFFF), iw = fb_iw0[half] + (tdyx >> 16);
+          const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+          dma4(rB, ldsB + (unsigned)buf * kBufBytes + (unsigned)((8 * wave + kk) * 512 + half * 256),
+               ok ? fb_pix[half] + (unsigned)(toff * 4) : kOOB);
+        }
+      }
+    }
+  };
+
   // BMODE 2: the staged k-step's values into its B tile (row k, columns 2 lane and 2 lane + 1: 512 consecutive bytes
   // per row and wave, conflict-free); the barrier at the next k-step's top publishes them
   auto commit = [&]() {
@@ -308,6 +377,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
     if (in_run(f_tile)) { f_k = seg_lo(f_tile); fetch_setup(f_tile); }
   }
   int buf = 0;
+  ESC_DPROF(0);
   for (; in_run(tile); tile += tile_step) {
     int cg, m0, p0;
     tile_coords(tile, cg, m0, p0);
@@ -316,23 +386,25 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x16{0};
+    ESC_DPROF(5);
     for (int ks = k_lo; ks < k_hi; ++ks, buf ^= 1) {
       // this wave's pieces of the step have landed (and the stores of the last epilogue are out) ...
 #ifdef ESCOIN_ABLATIONS
       if (!ESC_DENSE_ABL(a, 1))     // ESCOIN_DENSE_ABL: 1 no wait for the operands, 2 no operand traffic, 4 no MFMAs
 #endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ESC_DPROF(1);
       __syncthreads();   // ... everyone's have, and everyone is done with the other buffer
+      ESC_DPROF(2);
+      // the next k-step's operands: as one burst here (BMODE 2 and the experiments' ESCOIN_DENSE_SLOTS=0), or slot by
+      // slot between the MFMAs below
+      bool do_fetch = in_run(f_tile);
 #ifdef ESCOIN_ABLATIONS
-      if (!ESC_DENSE_ABL(a, 2))
+      if (ESC_DENSE_ABL(a, 2)) do_fetch = false;
 #endif
-      if (in_run(f_tile)) {
-        fetch(f_k, buf ^ 1);
-        if (++f_k == seg_hi(f_tile)) {
-          f_tile += tile_step;
-          if (in_run(f_tile)) { f_k = seg_lo(f_tile); fetch_setup(f_tile); }
-        }
-      }
+      const bool slotted = !STRIDED1 && a.fetch_slots;
+      if (do_fetch && !slotted) fetch(f_k, buf ^ 1);
+      ESC_DPROF(3);
       // fragments of k-group kg + 1 are read while the MFMAs of k-group kg run
       // lane (i, h): A rows wm * 64 + {0, 32} + i, k = 8 kg + 4 h + t; B columns wn * WN + 32 j + i
       const int ra = wm * 64 + li;
@@ -361,6 +433,10 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         const float a1[4] = {fa[s][1].x, fa[s][1].y, fa[s][1].z, fa[s][1].w};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+          if (do_fetch && slotted && 4 * kg + t < 8) {
+            fetch_slot(f_k, buf ^ 1, 4 * kg + t);
+            __builtin_amdgcn_sched_barrier(0);      // (the piece stays in front of this group's MFMAs)
+          }
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
             acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], fb[s][t][j], acc[0][j], 0, 0, 0);
@@ -369,6 +445,13 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         }
       }
       commit();       // (BMODE 2: the next step's B rows from the staging registers into the other buffer)
+      if (do_fetch) {
+        if (++f_k == seg_hi(f_tile)) {
+          f_tile += tile_step;
+          if (in_run(f_tile)) { f_k = seg_lo(f_tile); fetch_setup(f_tile); }
+        }
+      }
+      ESC_DPROF(4);
     }
     if (STREAMK) {
       // the lane's accumulators as 16 * NB quads: quad (i, j, r4) = acc[i][j][4 r4 .. 4 r4 + 3]
@@ -395,6 +478,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         __syncthreads();
         if (tid == 0) __hip_atomic_store((gu32 *)(a.sk_flag + blockIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         (void)kQuads;
+        ESC_DPROF(7);
         continue;     // (the run's last tile, walked first: the others are whole, or finished below)
       }
       if (k_lo > 0) {
@@ -439,6 +523,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
       }
     }
 
+    ESC_DPROF(7);
     // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
     // The bias of the lane's 32 rows is fetched in one go (a load per output, each followed by the
     // compiler's s_waitcnt vmcnt(0), would also wait for the previous STORE every time).
@@ -493,10 +578,11 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
           const int row = it * kRowsPerIt + r0;
           const float4 v = *reinterpret_cast<const float4 *>(&stage[row * WN + 4 * c4]);
           const int m = m0 + wm * 64 + 32 * i + row;
-          if (m < a.Mg && pq < a.P) *reinterpret_cast<float4 *>(oq + (size_t)m * ohw) = v;
+          if (m < a.Mg && pq < a.P && !ESC_DENSE_ABL(a, 8)) *reinterpret_cast<float4 *>(oq + (size_t)m * ohw) = v;      // (ESCOIN_DENSE_ABL bit 3: no stores)
         }
         asm volatile("" ::: "memory");
       }
+      ESC_DPROF(6);
       continue;
     }
 #pragma unroll
@@ -514,12 +600,15 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
           if (m >= a.Mg) continue;
           float v = acc[i][j][reg] + bv[i][reg];
           if (a.relu) v = fmaxf(v, 0.f);
-          obase[(size_t)m * ohw] = v;
+          if (!ESC_DENSE_ABL(a, 8)) obase[(size_t)m * ohw] = v;
         }
       }
     }
+    ESC_DPROF(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ESC_DPROF(6);
+  ESC_DPROF_DUMP
 }
 
 // Zeroes the stream-K flag words before a launch (see launch_dense for why this is not a memset).
@@ -652,6 +741,18 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   }
   a.group_mask = p->use_dense ? ~0ull : p->dense_mask;
   a.abl = ESC_ABL_KNOB("DENSE_ABL");
+  {
+    static const int slots_knob = (int)ESC_KNOB("DENSE_SLOTS", 1);
+    a.fetch_slots = slots_knob != 0 ? 1 : 0;
+  }
+  a.prof = nullptr;
+#ifdef ESCOIN_ABLATIONS
+  static unsigned long long *prof_buf = nullptr;
+  if (ESC_ABL_KNOB("PROF")) {
+    if (!prof_buf) ESCOIN_HIP_TRY(hipMalloc(&prof_buf, sizeof(unsigned long long) * (32 * 4096 + 4 * 4096)));
+    a.prof = prof_buf;
+  }
+#endif
   const int bm = g.Mg <= 64 ? 64 : 128;
   a.n_ptiles = (int)((P + kBN - 1) / kBN);
   a.n_mtiles = (g.Mg + bm - 1) / bm;
@@ -719,6 +820,36 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   }
 #undef ESC_DENSE_LAUNCH
   ESCOIN_HIP_TRY(hipGetLastError());
+#ifdef ESCOIN_ABLATIONS
+  if (a.prof && n_wg <= 4096) {
+    // (every launch while ESCOIN_PROF=1: synchronises -- a profiling run, not a timing run)
+    ESCOIN_HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> h((size_t)32 * 4096 + 4 * 4096);
+    ESCOIN_HIP_TRY(hipMemcpy(h.data(), a.prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    static const char *names[8] = {"start-up", "operand wait", "barrier", "fetch issue", "reads + MFMAs", "tile setup", "epilogue", "stream-K"};
+    double cat[8] = {0}, cyc = 0, rt = 0, first = 1e30, last = 0, mx[8] = {0};
+    for (long w = 0; w < n_wg; ++w) {
+      for (int i = 0; i < 8; ++i) {
+        double sum = 0;
+        for (int wv = 0; wv < 4; ++wv) sum += (double)h[((size_t)w * 4 + wv) * 8 + i];
+        cat[i] += sum / 4;
+        mx[i] = std::max(mx[i], sum / 4);
+      }
+      cyc += (double)h[(size_t)32 * 4096 + 4 * w];
+      rt += (double)h[(size_t)32 * 4096 + 4 * w + 1];
+      first = std::min(first, (double)h[(size_t)32 * 4096 + 4 * w + 2]);
+      last = std::max(last, (double)h[(size_t)32 * 4096 + 4 * w + 2] + (double)h[(size_t)32 * 4096 + 4 * w + 1]);
+    }
+    const double ghz = cyc / (rt * 10.0);
+    double tot = 0;
+    for (int i = 0; i < 8; ++i) tot += cat[i] / n_wg;
+    fprintf(stderr, "[dprof] %ld workgroups (%s, BM %d, %s), %ld tiles x %ld k-steps; workgroup life %.0f cycles = %.2f us @ %.3f GHz; first start to last end %.2f us\n",
+            n_wg, streamk ? "stream-K" : "tiles", bm, vec_b ? "pointwise 16-byte B" : "gathered B", tiles, nk, cyc / n_wg, rt / n_wg * 0.01, ghz, (last - first) * 0.01);
+    fprintf(stderr, "[dprof] mean wave cycles per workgroup by phase:");
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.0f (%.2f us, %.0f %%)", names[i], cat[i] / n_wg, cat[i] / n_wg / ghz * 1e-3, 100.0 * cat[i] / n_wg / std::max(1.0, tot));
+    fprintf(stderr, " | accounted %.0f %% of the workgroup life\n", 100.0 * tot / std::max(1.0, cyc / n_wg));
+  }
+#endif
   return ESCOIN_OK;
 }
 

@@ -9,11 +9,16 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=${PROF_OUT:-gpurun_out}/prof_${TAG}_${WL}
 rm -rf $OUT; mkdir -p $OUT
-ARGS="bench.py --workload $WL --steps 5 --warmup 2 --no-cpu"
+ARGS="bench.py --workload $WL --steps 5 --warmup 2 --no-cpu --no-extras"
 # (PMC passes: inputs generated with one call per layer, see bench.py device_images)
 export ESCOIN_BENCH_BULK_INPUTS=0
 # the kernel-stats pass runs bench.py with its default step counts (the command the driver times)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --workload $WL --no-cpu > $OUT/bench_stats.json 2> $OUT/bench_stats.log
+# (--no-extras: the other configurations and the sparsity sweep that the default ResNet run appends launch the SAME kernel
+#  names at other sparsities; without them the per-kernel averages are the headline's.  FULL=1 adds a pass of the whole command.)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --workload $WL --no-cpu --no-extras > $OUT/bench_stats.json 2> $OUT/bench_stats.log
+if [ "${FULL:-0}" = "1" ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_full -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $OUT/bench_full.json 2> $OUT/bench_full.log
+fi
 export ESCOIN_BENCH_BULK_INPUTS=1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > /dev/null 2> $OUT/pmc_write.log

@@ -100,6 +100,14 @@ def main():
     if traffic:
         import subprocess
         import time
+        # which configuration the counters were collected on: bench.py only uses the file for exactly this one
+        try:
+            cfg = json.load(open(sys.argv[3]))["config"] if len(sys.argv) > 3 else {}
+            if "per_gpu_batch" in cfg:
+                traffic["_batch"] = int(cfg["per_gpu_batch"])
+                traffic["_sparsity_pct"] = int(cfg["sparsity_pct"])
+        except Exception:
+            pass
         try:
             traffic["_commit"] = subprocess.run(["git", "log", "-1", "--format=%h"], stdout=subprocess.PIPE,
                                                 stderr=subprocess.DEVNULL, timeout=10).stdout.decode().strip() or None
