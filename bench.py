@@ -213,7 +213,7 @@ def build_layers(be, pkg, synth, shapes, rank, world, args=None, dist_on=None):
             else:
                 entries[k][1].set_csr(*received[k])
             per_layer[k] = (time.perf_counter() - t1) * 1e3
-        n_workers = max(1, min(int(getattr(args, "receive_threads", 4) or 1), len(entries)))
+        n_workers = max(1, min(int(getattr(args, "receive_threads", 1) or 1), len(entries)))
         be.synchronize()
         t0 = time.perf_counter()
         if n_workers > 1 and not test_be(be):
@@ -361,17 +361,40 @@ def host_cpu_info():
 
 
 _HOST_INFO = None
+_ALLOWED_CPUS = None      # the affinity mask the process started with (main(), before any OpenMP runtime pinned this thread)
 
 
 def product_cpu_mode(pkg, synth, shapes, threads, budget_s):
     """The PRODUCT's own Caffe::CPU mode (escoin_forward_cpu, csrc/sconv_cpu*.cpp -- not the oracle, not oracle/_ref)
     on the same shapes and host cores, reported beside the reference CPU numbers: images/s over the whole layer set."""
     per_image, share = 0.0, budget_s / max(1, len(shapes))
+    # The library's host threads inherit the affinity of the thread that starts them -- and this thread was pinned to ONE
+    # core by the OpenMP runtime (OMP_PROC_BIND=close for the reference legs binds the initial thread when libgomp loads).
+    # For this leg it gets back the mask the process started with (main() recorded it before anything loaded OpenMP);
+    # without that 16 pool threads shared one core (first r06 run: 230 images/s instead of the number below).
+    pinned = None
+    if _ALLOWED_CPUS:
+        try:
+            pinned = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, _ALLOWED_CPUS)
+        except (AttributeError, OSError):
+            pinned = None
+    try:
+        return _product_cpu_mode(pkg, synth, shapes, threads, per_image, share)
+    finally:
+        if pinned:
+            try:
+                os.sched_setaffinity(0, pinned)
+            except OSError:
+                pass
+
+
+def _product_cpu_mode(pkg, synth, shapes, threads, per_image, share):
     for k, s in enumerate(shapes):
         plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
         plan.weight_align_cpu(synth.pruned_weights(s, 1000 + k, WEIGHT_DIST))
         b = synth.bias_vector(s, 2000 + k)
-        n = max(2 * threads, 32)
+        n = min(256, max(16 * threads, 64))      # (whole-batch calls like the reference legs: 16 images per thread)
         x = synth.activations(s, 3000 + k, 0, n)
         t0 = time.perf_counter()                                  # warm: threads, page faults, padded buffers -- and the
         while time.perf_counter() - t0 < (1.5 if k == 0 else 0.2):   # scheduler: a VM host may take a second to spread a
@@ -1036,9 +1059,10 @@ def parse_args(argv=None):
     ap.add_argument("--broadcast", default="aligned", choices=["aligned", "csr"],
                     help="N > 1: what rank 0 broadcasts per layer -- the aligned form incl. the generated code (receivers "
                          "load it as it is), or the CSR alone (receivers run their own WeightAlign tail)")
-    ap.add_argument("--receive-threads", type=int, default=4,
+    ap.add_argument("--receive-threads", type=int, default=1,
                     help="N > 1: host threads a receiver imports its layers on (the code object loads of different plans "
-                         "overlap; 1 = layer by layer)")
+                         "can overlap: tools/dbg/import_threads.py; in the bench's own flow 4 threads measured SLOWER than 1 -- "
+                         "66 against 48 ms for the 16 ResNet layers, profiles/r06_receive_threads.md -- so the default is layer by layer)")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue the step's (independent) layers round robin on this many HIP streams; 1 = one stream, as "
                          "the reference launches its layers (the default and the judged line)")
@@ -1118,8 +1142,12 @@ def main(backend_factory=None, script=None):
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], script))      # nothing below runs in the launcher
     # the host's CPU share is read BEFORE any OpenMP runtime exists: with OMP_PROC_BIND set, the
     # runtime torch loads pins this thread to one core and the affinity mask then reads "2 threads"
-    global _HOST_INFO
+    global _HOST_INFO, _ALLOWED_CPUS
     _HOST_INFO = host_cpu_info()
+    try:
+        _ALLOWED_CPUS = set(os.sched_getaffinity(0))
+    except AttributeError:
+        _ALLOWED_CPUS = None
     # OpenMP placement for the cpu_baseline leg must be in the environment before libgomp loads
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
