@@ -175,22 +175,23 @@ static void run_unit_stride(const GroupJob<T> &J) {
   const int per_tile = (nvec + ntiles - 1) / ntiles;     // evenly sized tiles (14 x 14: 7 + 7 vectors, not 12 + 2)
   const bool direct = J.PW == J.OW;                      // no dropped columns: virtual pixel == output index
   // the runs of real outputs of one tile (at most rows-in-a-tile + 1 of them)
-  Seg segs[kMaxVecs * 16 + 2];
+  Seg segs[kMaxVecs * 16 + 8];
   for (int t0 = 0; t0 < nvec; t0 += per_tile) {
     const int nv = std::min(per_tile, nvec - t0);
     const int q0 = t0 * L, q1 = std::min(Q, q0 + nv * L);
+    // The runs of real outputs inside the tile, row by row: output row oh owns the virtual pixels [oh * PW, oh * PW + OW).
+    // (With pad_w > (KW - 1) * dil_w / 2 a row has MORE outputs than the padded pitch, OW > PW: its last outputs are the
+    //  virtual pixels the next row starts with -- the same addresses, the same sums: the shared-halo layout's own
+    //  wrap-around, math_functions.cpp:162-174 -- so rows overlap on the virtual axis and each takes its own copy.)
     int nseg = 0;
-    for (int q = q0; q < q1;) {
-      const int oh = q / J.PW, ow = q - oh * J.PW;
-      const int run = std::min(q1 - q, J.PW - ow);
-      const int keep = std::min(run, J.OW - ow);
-      if (keep > 0) {
-        segs[nseg].dst = oh * J.OW + ow;
-        segs[nseg].src = q - q0;
-        segs[nseg].len = keep;
-        ++nseg;
-      }
-      q += run;
+    const int oh_lo = std::max(0, (q0 - J.OW + J.PW) / J.PW), oh_hi = std::min(J.OH - 1, (q1 - 1) / J.PW);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const int lo = std::max(q0, oh * J.PW), hi = std::min(q1, oh * J.PW + J.OW);
+      if (hi <= lo) continue;
+      segs[nseg].dst = oh * J.OW + (lo - oh * J.PW);
+      segs[nseg].src = lo - q0;
+      segs[nseg].len = hi - lo;
+      ++nseg;
     }
     const int tail = q1 - (q0 + (nv - 1) * L);           // valid lanes of the last vector, 1 .. L
     const int masked_n = (J.exact_reads && tail < L) ? tail : 0;

@@ -89,6 +89,8 @@ def test_f64_and_f32_oracles_agree_where_both_are_exact(oracle):
     (1, 2, 6, 9, 2, 3, 3, 0, 1, 1, 1, 1, 1, 1),        # pad_h == 0 < pad_w, stride 1
     (5, 1, 1, 1, 2, 1, 1, 0, 0, 1, 1, 1, 1, 1),        # 1 x 1 images
     (2, 2, 5, 40, 2, 5, 5, 2, 2, 1, 1, 1, 1, 1),       # wide rows
+    (4, 1, 12, 29, 3, 4, 1, 2, 3, 1, 1, 2, 1, 1),      # pad_w > (KW - 1) / 2: MORE outputs per row than the padded pitch (found by the seeded sweep below)
+    (2, 3, 6, 5, 4, 3, 3, 3, 3, 1, 1, 1, 1, 1),        # the same with a 3x3 kernel and pad 3
 ])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_cpu_forward_geometries_vs_oracle(pkg, oracle, geom, dtype):
@@ -217,3 +219,40 @@ def test_product_library_does_not_know_the_oracle(pkg):
         for line in text.splitlines():
             if "#include" in line or "dlopen" in line:
                 assert "oracle" not in line, (fn, line)
+
+
+@pytest.mark.parametrize("seed", [20261004, 7])
+def test_cpu_forward_seeded_random_geometries(pkg, oracle, seed):
+    """A seeded slice of random geometries (kernel 1..5 per axis, strides 1..3, pads 0..3, dilation 1..2, groups, odd
+    widths, batches below and above the thread count) through the product's CPU mode against the oracle: bit-equal,
+    float and double, with and without bias / ReLU."""
+    rng = np.random.RandomState(seed)
+    done = 0
+    while done < 60:
+        grp = int(rng.choice([1, 1, 2, 3]))
+        Cg, Mg = int(rng.randint(1, 7)), int(rng.randint(1, 9))
+        KH, KW = int(rng.randint(1, 6)), int(rng.randint(1, 6))
+        sh, sw = int(rng.choice([1, 1, 1, 2, 3])), int(rng.choice([1, 1, 1, 2, 3]))
+        dh, dw = int(rng.choice([1, 1, 2])), int(rng.choice([1, 1, 2]))
+        ph, pw = int(rng.randint(0, 4)), int(rng.randint(0, 4))
+        H, W = int(rng.randint(1, 24)), int(rng.randint(1, 40))
+        if (H + 2 * ph - (dh * (KH - 1) + 1)) < 0 or (W + 2 * pw - (dw * (KW - 1) + 1)) < 0:
+            continue
+        N = int(rng.randint(1, 7))
+        C_, M = Cg * grp, Mg * grp
+        dtype = np.float64 if rng.rand() < 0.4 else np.float32
+        dens = float(rng.choice([0.05, 0.3, 0.7, 1.0]))
+        x = rng.uniform(-1, 1, (N, C_, H, W)).astype(dtype)
+        w = (rng.uniform(-1, 1, (M, Cg, KH, KW)) * (rng.uniform(size=(M, Cg, KH, KW)) < dens)).astype(dtype)
+        b = rng.uniform(-0.1, 0.1, M).astype(dtype) if rng.rand() < 0.7 else None
+        relu = bool(rng.rand() < 0.3)
+        g = oracle.geom(C_, H, W, M, KH, KW, ph, pw, sh, sw, dh, dw, grp)
+        fwd = oracle.conv_forward_f64 if dtype == np.float64 else oracle.conv_forward
+        want = fwd(g, x, w, b, relu=relu, gate=False)
+        plan = pkg.Plan(pkg.ConvDesc(N, C_, H, W, M, KH, KW, ph, pw, sh, sw, dh, dw, grp, int(b is not None), int(relu)))
+        plan.weight_align_cpu(w)
+        got = plan.forward_cpu(x, b, n_threads=int(rng.choice([1, 2, 5])))
+        assert np.array_equal(got, want), dict(N=N, C=C_, H=H, W=W, M=M, KH=KH, KW=KW, ph=ph, pw=pw, sh=sh, sw=sw, dh=dh, dw=dw,
+                                                grp=grp, dtype=str(dtype), relu=relu, bias=b is not None)
+        plan.close()
+        done += 1
