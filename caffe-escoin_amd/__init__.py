@@ -39,7 +39,7 @@ API_SYMBOLS = [
     "escoin_gpu_sconv_f64", "escoin_copy_input_data_f64", "escoin_gpu_sparse_csrmm_f64",
     "escoin_gpu_sparse_dense2csr_f64",
     # Caffe::CPU mode
-    "escoin_cpu_kernel_name", "escoin_weight_align_cpu", "escoin_weight_align_cpu_f64",
+    "escoin_cpu_kernel_name", "escoin_cpu_kernel_select", "escoin_weight_align_cpu", "escoin_weight_align_cpu_f64",
     "escoin_forward_cpu", "escoin_forward_cpu_f64", "escoin_cpu_sconv", "escoin_cpu_sconv_f64",
     "escoin_cpu_sparse_dense2csr", "escoin_cpu_sparse_dense2csr_f64",
 ]
@@ -161,6 +161,8 @@ def lib():
             L.escoin_gpu_sparse_csrmm_f64.argtypes = [ip, ip, ip, ip, real, vp, vp, vp, vp, real, vp, vp]
     L.escoin_cpu_kernel_name.restype = cp
     L.escoin_cpu_kernel_name.argtypes = []
+    L.escoin_cpu_kernel_select.restype = ip
+    L.escoin_cpu_kernel_select.argtypes = [cp]
     _lib = L
     return L
 
@@ -172,6 +174,11 @@ def check(rc, what="escoin call"):
 
 def device_count():
     return lib().escoin_device_count()
+
+
+def cpu_kernel_select(which):
+    """Pin the host kernel's flavour ("avx2", "avx512", "auto"); raises when this CPU lacks it."""
+    check(lib().escoin_cpu_kernel_select(which.encode()), "escoin_cpu_kernel_select(%s)" % which)
 
 
 def cpu_kernel_name():

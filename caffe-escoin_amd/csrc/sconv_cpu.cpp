@@ -44,9 +44,12 @@ static Isa detect_isa() {
   return kNone;
 }
 
+static std::atomic<int> g_isa_override{-1};      // escoin_cpu_kernel_select: -1 = what the CPU reports
+
 static Isa isa() {
   static const Isa v = detect_isa();
-  return v;
+  const int o = g_isa_override.load(std::memory_order_relaxed);
+  return o < 0 ? v : (Isa)o;
 }
 
 template <typename T>
@@ -375,6 +378,24 @@ const char *escoin_cpu_kernel_name(void) {
     case cpu::kAvx2: return "escoin_cpu_sconv_avx2";
     default: return "(no AVX2 + FMA: CPU path unavailable)";
   }
+}
+
+int escoin_cpu_kernel_select(const char *which) {
+  if (!which) return fail(ESCOIN_EINVAL, "null argument");
+  cpu::g_isa_override.store(-1);
+  const cpu::Isa best = cpu::isa();
+  if (!strcmp(which, "auto")) return ESCOIN_OK;
+  if (!strcmp(which, "avx2")) {
+    if (best == cpu::kNone) return fail(ESCOIN_ENODEVICE, "this CPU has no AVX2 + FMA");
+    cpu::g_isa_override.store((int)cpu::kAvx2);
+    return ESCOIN_OK;
+  }
+  if (!strcmp(which, "avx512")) {
+    if (best != cpu::kAvx512) return fail(ESCOIN_ENODEVICE, "this CPU has no AVX-512 (F, VL, DQ)");
+    cpu::g_isa_override.store((int)cpu::kAvx512);
+    return ESCOIN_OK;
+  }
+  return fail(ESCOIN_EINVAL, "escoin_cpu_kernel_select: \"auto\", \"avx2\" or \"avx512\"");
 }
 
 int escoin_weight_align_cpu(escoin_plan *p, const float *dense_w) {

@@ -315,6 +315,10 @@ ESCOIN_API int escoin_gpu_sparse_dense2csr_f64(int M, int N, const double *A, in
 
 /* Which flavour of the host kernel this machine runs ("escoin_cpu_sconv_avx512" / "..._avx2"). */
 ESCOIN_API const char *escoin_cpu_kernel_name(void);
+/* Pins the flavour for the calls that follow, process-wide: "avx2", "avx512" (ESCOIN_ENODEVICE when this CPU lacks it)
+ * or "auto" (what the CPU reports; the default).  Results are bit-identical in every flavour; the tests use this to run
+ * both on one machine. */
+ESCOIN_API int escoin_cpu_kernel_select(const char *which);
 
 /* WeightAlign() in CPU mode: dense blobs_[0] on the host -> the plan's host CSR.  No device work; a plan aligned this
  * way serves escoin_forward_cpu only (escoin_forward needs escoin_weight_align).  Conversely escoin_forward_cpu also

@@ -17,6 +17,18 @@ from conftest import Golden, golden_params, naive_conv, rel_err
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True, params=["avx2", "avx512"])
+def cpu_flavour(request, pkg):
+    """Every test of this file runs once per flavour of the host kernel this machine can run."""
+    try:
+        pkg.cpu_kernel_select(request.param)
+    except pkg.EscoinError:
+        pytest.skip("this CPU has no %s" % request.param)
+    assert pkg.cpu_kernel_name().endswith(request.param)
+    yield request.param
+    pkg.cpu_kernel_select("auto")
+
+
 def _plan_cpu(pkg, g, w, **kw):
     plan = pkg.Plan(g.desc(pkg, **kw))
     plan.weight_align_cpu(w)
