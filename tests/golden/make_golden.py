@@ -42,6 +42,13 @@ CASES = [
     S("nonsquare_k3x5_s1x2_p1x2", 2, 5, 9, 11, 6, 3, KW=5, pad=1, pad_w=2, stride=1, stride_w=2,
       sparsity=0.5),
     S("empty_rows_k3p1", 1, 4, 5, 5, 8, 3, pad=1, sparsity=0.97),
+    # (round 6) padding in one direction only, pad_h == 0 < pad_w: the geometry class whose last row's right padding lies
+    # behind the reference's own allocation (base_conv_layer.cpp:71).  The reference kernel runs here on a buffer with the
+    # pad_w zero floats of slack the oracle defines (oracle_padded_len), i.e. its arithmetic with the padding the layer
+    # specifies; and the mirror case pad_w == 0 < pad_h, which needs no slack.
+    S("padw_only_k1x3", 2, 4, 6, 9, 5, 1, KW=3, pad=0, pad_w=1, sparsity=0.5),
+    S("padw_only_k3x5_p0x2", 2, 3, 7, 10, 4, 3, KW=5, pad=0, pad_w=2, sparsity=0.6),
+    S("padh_only_k3x1", 2, 4, 6, 9, 5, 3, KW=1, pad=1, pad_w=0, sparsity=0.5),
 ]
 
 
@@ -50,8 +57,11 @@ def main():
         oracle.build()
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref is not built (needs /root/reference)")
+    only_new = "--only-new" in sys.argv      # (keeps the committed files byte-identical: np.savez_compressed is not)
     for k, s in enumerate(CASES):
         seed = 1000 + 17 * k
+        if only_new and os.path.exists(os.path.join(HERE, s.name + ".npz")):
+            continue
         w = synth.pruned_weights(s, seed)
         b = synth.bias_vector(s, seed + 1)
         x = synth.activations(s, seed + 2)
