@@ -43,9 +43,12 @@
 //   2 k-step top: workgroup barrier                                 3 issuing the next k-step's fetch (LDS-DMA / gather)
 //   4 fragment reads + MFMAs                                        5 between tiles: coordinates, accumulator reset
 //   6 epilogue: bias, transpose through LDS, stores                 7 stream-K hand-over / fix-up
-#define ESC_DPROF_DECL unsigned long long dpt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpl_ = __builtin_readcyclecounter(); \
+#define ESC_DPROF_DECL int dpe_ = 0; unsigned long long dpt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpl_ = __builtin_readcyclecounter(); \
   const unsigned long long dpc0_ = dpl_, dpr0_ = __builtin_amdgcn_s_memrealtime();
 #define ESC_DPROF(i) do { if (a.prof) { const unsigned long long n_ = __builtin_readcyclecounter(); dpt_[i] += n_ - dpl_; dpl_ = n_; } } while (0)
+// ... and, for the step between a CU's two workgroups (profiles/r06_dense_stamps.md section 5): the 100 MHz times at which the
+// epilogues of a workgroup's first 24 tiles start and end (wave 0)
+#define ESC_DPROF_EPI(which) do { if (a.prof && threadIdx.x == 0 && dpe_ < 24) { a.prof[(size_t)36 * 4096 + ((size_t)blockIdx.x * 24 + dpe_) * 2 + (which)] = __builtin_amdgcn_s_memrealtime(); if (which) ++dpe_; } } while (0)
 #define ESC_DPROF_DUMP                                                                                              \
   if (a.prof && (threadIdx.x & 63) == 0) {                                                                          \
     for (int i_ = 0; i_ < 8; ++i_) a.prof[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = dpt_[i_];       \
@@ -59,6 +62,7 @@
 #define ESC_DENSE_ABL(a, bits) (0)
 #define ESC_DPROF_DECL
 #define ESC_DPROF(i)
+#define ESC_DPROF_EPI(which)
 #define ESC_DPROF_DUMP
 #endif
 
@@ -524,6 +528,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
     }
 
     ESC_DPROF(7);
+    ESC_DPROF_EPI(0);
     // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
     // The bias of the lane's 32 rows is fetched in one go (a load per output, each followed by the
     // compiler's s_waitcnt vmcnt(0), would also wait for the previous STORE every time).
@@ -583,6 +588,7 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         asm volatile("" ::: "memory");
       }
       ESC_DPROF(6);
+      ESC_DPROF_EPI(1);
       continue;
     }
 #pragma unroll
@@ -749,7 +755,8 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
 #ifdef ESCOIN_ABLATIONS
   static unsigned long long *prof_buf = nullptr;
   if (ESC_ABL_KNOB("PROF")) {
-    if (!prof_buf) ESCOIN_HIP_TRY(hipMalloc(&prof_buf, sizeof(unsigned long long) * (32 * 4096 + 4 * 4096)));
+    if (!prof_buf) ESCOIN_HIP_TRY(hipMalloc(&prof_buf, sizeof(unsigned long long) * (36 * 4096 + 48 * 4096)));
+    ESCOIN_HIP_TRY(hipMemsetAsync(prof_buf, 0, sizeof(unsigned long long) * (36 * 4096 + 48 * 4096), stream));
     a.prof = prof_buf;
   }
 #endif
@@ -824,7 +831,7 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   if (a.prof && n_wg <= 4096) {
     // (every launch while ESCOIN_PROF=1: synchronises -- a profiling run, not a timing run)
     ESCOIN_HIP_TRY(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> h((size_t)32 * 4096 + 4 * 4096);
+    std::vector<unsigned long long> h((size_t)36 * 4096 + 48 * 4096);
     ESCOIN_HIP_TRY(hipMemcpy(h.data(), a.prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
     static const char *names[8] = {"start-up", "operand wait", "barrier", "fetch issue", "reads + MFMAs", "tile setup", "epilogue", "stream-K"};
     double cat[8] = {0}, cyc = 0, rt = 0, first = 1e30, last = 0, mx[8] = {0};
@@ -848,6 +855,31 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
     fprintf(stderr, "[dprof] mean wave cycles per workgroup by phase:");
     for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.0f (%.2f us, %.0f %%)", names[i], cat[i] / n_wg, cat[i] / n_wg / ghz * 1e-3, 100.0 * cat[i] / n_wg / std::max(1.0, tot));
     fprintf(stderr, " | accounted %.0f %% of the workgroup life\n", 100.0 * tot / std::max(1.0, cyc / n_wg));
+    // Are the two workgroups of a CU (i and i + n / 2: tools/probes/probe_hwid.hip) in step?  Over their tiles 4 .. 23: the time both spend in their
+    // epilogues at once / the time either's epilogue lasts.  1 = lockstep, ~ epilogue share of the tile period = independent phases, 0 = alternating.
+    if (n_wg % 2 == 0 && n_wg >= 2) {
+      const unsigned long long *ep = h.data() + (size_t)36 * 4096;
+      double both = 0, one = 0, period = 0, elen = 0;
+      long np = 0;
+      for (long w = 0; w < n_wg / 2; ++w) {
+        const unsigned long long *A = ep + (size_t)w * 48, *B = ep + (size_t)(w + n_wg / 2) * 48;
+        if (!A[2 * 23 + 1] || !B[2 * 23 + 1]) continue;
+        for (int t = 4; t < 23; ++t) {
+          const double a0 = (double)A[2 * t], a1 = (double)A[2 * t + 1];
+          one += a1 - a0;
+          for (int u = 0; u < 24; ++u) {
+            const double b0 = (double)B[2 * u], b1 = (double)B[2 * u + 1];
+            both += std::max(0.0, std::min(a1, b1) - std::max(a0, b0));
+          }
+          period += (double)A[2 * (t + 1)] - a0;
+          elen += a1 - a0;
+          ++np;
+        }
+      }
+      if (np > 0)
+        fprintf(stderr, "[dprof] CU partners (workgroups i, i + %ld), tiles 4-22: tile period %.2f us, epilogue %.2f us = %.0f %% of it; partner in its epilogue during %.0f %% of a workgroup's epilogue time (independent phases would give ~%.0f %%, lockstep 100 %%)\n",
+                n_wg / 2, period / np * 0.01, elen / np * 0.01, 100.0 * elen / period, 100.0 * both / one, 100.0 * elen / period);
+    }
   }
 #endif
   return ESCOIN_OK;
