@@ -43,19 +43,19 @@
 //   2 k-step top: workgroup barrier                                 3 issuing the next k-step's fetch (LDS-DMA / gather)
 //   4 fragment reads + MFMAs                                        5 between tiles: coordinates, accumulator reset
 //   6 epilogue: bias, transpose through LDS, stores                 7 stream-K hand-over / fix-up
-#define ESC_DPROF_DECL int dpe_ = 0; unsigned long long dpt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpl_ = __builtin_readcyclecounter(); \
+#define ESC_DPROF_DECL int dpe_ = 0; unsigned long long dpt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long dpl_ = __builtin_readcyclecounter(); \
   const unsigned long long dpc0_ = dpl_, dpr0_ = __builtin_amdgcn_s_memrealtime();
 #define ESC_DPROF(i) do { if (a.prof) { const unsigned long long n_ = __builtin_readcyclecounter(); dpt_[i] += n_ - dpl_; dpl_ = n_; } } while (0)
 // ... and, for the step between a CU's two workgroups (profiles/r06_dense_stamps.md section 5): the 100 MHz times at which the
 // epilogues of a workgroup's first 24 tiles start and end (wave 0)
-#define ESC_DPROF_EPI(which) do { if (a.prof && threadIdx.x == 0 && dpe_ < 24) { a.prof[(size_t)36 * 4096 + ((size_t)blockIdx.x * 24 + dpe_) * 2 + (which)] = __builtin_amdgcn_s_memrealtime(); if (which) ++dpe_; } } while (0)
+#define ESC_DPROF_EPI(which) do { if (a.prof && threadIdx.x == 0 && dpe_ < 24) { a.prof[(size_t)68 * 4096 + ((size_t)blockIdx.x * 24 + dpe_) * 2 + (which)] = __builtin_amdgcn_s_memrealtime(); if (which) ++dpe_; } } while (0)
 #define ESC_DPROF_DUMP                                                                                              \
   if (a.prof && (threadIdx.x & 63) == 0) {                                                                          \
-    for (int i_ = 0; i_ < 8; ++i_) a.prof[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = dpt_[i_];       \
+    for (int i_ = 0; i_ < 10; ++i_) a.prof[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + i_] = dpt_[i_];     \
     if (threadIdx.x == 0) {                                                                                         \
-      a.prof[(size_t)32 * 4096 + 4 * (size_t)blockIdx.x] = __builtin_readcyclecounter() - dpc0_;                    \
-      a.prof[(size_t)32 * 4096 + 4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - dpr0_;            \
-      a.prof[(size_t)32 * 4096 + 4 * (size_t)blockIdx.x + 2] = dpr0_;                                               \
+      a.prof[(size_t)64 * 4096 + 4 * (size_t)blockIdx.x] = __builtin_readcyclecounter() - dpc0_;                    \
+      a.prof[(size_t)64 * 4096 + 4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - dpr0_;            \
+      a.prof[(size_t)64 * 4096 + 4 * (size_t)blockIdx.x + 2] = dpr0_;                                               \
     }                                                                                                               \
   }
 #else
@@ -556,6 +556,10 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
       // says everybody is done reading it, the barrier at the next k-step's top that everybody is
       // done with the staging.  A wave transposes its own 32 x WN half-tiles: no cross-wave traffic.
       __syncthreads();
+#ifdef ESCOIN_ABLATIONS
+      unsigned long long dps_ = 0;
+      if (a.prof) { dps_ = __builtin_readcyclecounter(); dpt_[8] += dps_ - dpl_; }      // (since the last stamp: bias, pin, barrier)
+#endif
       float *stage = &sAB[buf ^ 1][wave * 32 * WN];
       constexpr int kQPR = WN / 4;                     // quads per staged row
       constexpr int kRowsPerIt = 64 / kQPR;            // rows one 64-lane read covers
@@ -578,15 +582,29 @@ __global__ void __launch_bounds__(256, 2) escoin_dense_mfma_kernel(DenseArgs a) 
         // (the wave reads back what it wrote itself: LDS operations of a wave complete in order; the
         // compiler must keep the order too)
         asm volatile("" ::: "memory");
+        // all of the half-tile's quads first, THEN the stores: read and stored one at a time (a predicated block each: read, wait
+        // for LDS, store) the LDS latency stood 16 times in every tile's epilogue -- 25 % of a K = 64 layer's wave life
+        // (profiles/r06_dense_stamps.md section 6)
+        float4 vq[32 / kRowsPerIt];
+#pragma unroll
+        for (int it = 0; it < 32 / kRowsPerIt; ++it)
+          vq[it] = *reinterpret_cast<const float4 *>(&stage[(it * kRowsPerIt + r0) * WN + 4 * c4]);
+        // (pinned: left alone, the compiler sinks every read into the predicated block of its store again)
+#pragma unroll
+        for (int it = 0; it < 32 / kRowsPerIt; it += 4)
+          asm volatile("" : "+v"(vq[it].x), "+v"(vq[it].y), "+v"(vq[it].z), "+v"(vq[it].w), "+v"(vq[it + 1].x), "+v"(vq[it + 1].y),
+                            "+v"(vq[it + 1].z), "+v"(vq[it + 1].w), "+v"(vq[it + 2].x), "+v"(vq[it + 2].y), "+v"(vq[it + 2].z), "+v"(vq[it + 2].w),
+                            "+v"(vq[it + 3].x), "+v"(vq[it + 3].y), "+v"(vq[it + 3].z), "+v"(vq[it + 3].w));
 #pragma unroll
         for (int it = 0; it < 32 / kRowsPerIt; ++it) {
-          const int row = it * kRowsPerIt + r0;
-          const float4 v = *reinterpret_cast<const float4 *>(&stage[row * WN + 4 * c4]);
-          const int m = m0 + wm * 64 + 32 * i + row;
-          if (m < a.Mg && pq < a.P && !ESC_DENSE_ABL(a, 8)) *reinterpret_cast<float4 *>(oq + (size_t)m * ohw) = v;      // (ESCOIN_DENSE_ABL bit 3: no stores)
+          const int m = m0 + wm * 64 + 32 * i + it * kRowsPerIt + r0;
+          if (m < a.Mg && pq < a.P && !ESC_DENSE_ABL(a, 8)) *reinterpret_cast<float4 *>(oq + (size_t)m * ohw) = vq[it];      // (ESCOIN_DENSE_ABL bit 3: no stores)
         }
         asm volatile("" ::: "memory");
       }
+#ifdef ESCOIN_ABLATIONS
+      if (a.prof) dpt_[9] += __builtin_readcyclecounter() - dps_;
+#endif
       ESC_DPROF(6);
       ESC_DPROF_EPI(1);
       continue;
@@ -755,8 +773,8 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
 #ifdef ESCOIN_ABLATIONS
   static unsigned long long *prof_buf = nullptr;
   if (ESC_ABL_KNOB("PROF")) {
-    if (!prof_buf) ESCOIN_HIP_TRY(hipMalloc(&prof_buf, sizeof(unsigned long long) * (36 * 4096 + 48 * 4096)));
-    ESCOIN_HIP_TRY(hipMemsetAsync(prof_buf, 0, sizeof(unsigned long long) * (36 * 4096 + 48 * 4096), stream));
+    if (!prof_buf) ESCOIN_HIP_TRY(hipMalloc(&prof_buf, sizeof(unsigned long long) * (68 * 4096 + 48 * 4096)));
+    ESCOIN_HIP_TRY(hipMemsetAsync(prof_buf, 0, sizeof(unsigned long long) * (68 * 4096 + 48 * 4096), stream));
     a.prof = prof_buf;
   }
 #endif
@@ -831,34 +849,35 @@ int launch_dense(const escoin_plan *p, const float *bottom, const float *bias, f
   if (a.prof && n_wg <= 4096) {
     // (every launch while ESCOIN_PROF=1: synchronises -- a profiling run, not a timing run)
     ESCOIN_HIP_TRY(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> h((size_t)36 * 4096 + 48 * 4096);
+    std::vector<unsigned long long> h((size_t)68 * 4096 + 48 * 4096);
     ESCOIN_HIP_TRY(hipMemcpy(h.data(), a.prof, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-    static const char *names[8] = {"start-up", "operand wait", "barrier", "fetch issue", "reads + MFMAs", "tile setup", "epilogue", "stream-K"};
-    double cat[8] = {0}, cyc = 0, rt = 0, first = 1e30, last = 0, mx[8] = {0};
+    static const char *names[10] = {"start-up", "operand wait", "barrier", "fetch issue", "reads + MFMAs", "tile setup", "epilogue", "stream-K",
+                                    "epilogue: bias + first barrier", "epilogue: the rest"};
+    double cat[10] = {0}, cyc = 0, rt = 0, first = 1e30, last = 0, mx[10] = {0};
     for (long w = 0; w < n_wg; ++w) {
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 10; ++i) {
         double sum = 0;
-        for (int wv = 0; wv < 4; ++wv) sum += (double)h[((size_t)w * 4 + wv) * 8 + i];
+        for (int wv = 0; wv < 4; ++wv) sum += (double)h[((size_t)w * 4 + wv) * 16 + i];
         cat[i] += sum / 4;
         mx[i] = std::max(mx[i], sum / 4);
       }
-      cyc += (double)h[(size_t)32 * 4096 + 4 * w];
-      rt += (double)h[(size_t)32 * 4096 + 4 * w + 1];
-      first = std::min(first, (double)h[(size_t)32 * 4096 + 4 * w + 2]);
-      last = std::max(last, (double)h[(size_t)32 * 4096 + 4 * w + 2] + (double)h[(size_t)32 * 4096 + 4 * w + 1]);
+      cyc += (double)h[(size_t)64 * 4096 + 4 * w];
+      rt += (double)h[(size_t)64 * 4096 + 4 * w + 1];
+      first = std::min(first, (double)h[(size_t)64 * 4096 + 4 * w + 2]);
+      last = std::max(last, (double)h[(size_t)64 * 4096 + 4 * w + 2] + (double)h[(size_t)64 * 4096 + 4 * w + 1]);
     }
     const double ghz = cyc / (rt * 10.0);
     double tot = 0;
-    for (int i = 0; i < 8; ++i) tot += cat[i] / n_wg;
+    for (int i = 0; i < 8; ++i) tot += cat[i] / n_wg;      // (8 and 9 split category 6: they are reported, not added)
     fprintf(stderr, "[dprof] %ld workgroups (%s, BM %d, %s), %ld tiles x %ld k-steps; workgroup life %.0f cycles = %.2f us @ %.3f GHz; first start to last end %.2f us\n",
             n_wg, streamk ? "stream-K" : "tiles", bm, vec_b ? "pointwise 16-byte B" : "gathered B", tiles, nk, cyc / n_wg, rt / n_wg * 0.01, ghz, (last - first) * 0.01);
     fprintf(stderr, "[dprof] mean wave cycles per workgroup by phase:");
-    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.0f (%.2f us, %.0f %%)", names[i], cat[i] / n_wg, cat[i] / n_wg / ghz * 1e-3, 100.0 * cat[i] / n_wg / std::max(1.0, tot));
+    for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.0f (%.2f us, %.0f %%)", names[i], cat[i] / n_wg, cat[i] / n_wg / ghz * 1e-3, 100.0 * cat[i] / n_wg / std::max(1.0, tot));
     fprintf(stderr, " | accounted %.0f %% of the workgroup life\n", 100.0 * tot / std::max(1.0, cyc / n_wg));
     // Are the two workgroups of a CU (i and i + n / 2: tools/probes/probe_hwid.hip) in step?  Over their tiles 4 .. 23: the time both spend in their
     // epilogues at once / the time either's epilogue lasts.  1 = lockstep, ~ epilogue share of the tile period = independent phases, 0 = alternating.
     if (n_wg % 2 == 0 && n_wg >= 2) {
-      const unsigned long long *ep = h.data() + (size_t)36 * 4096;
+      const unsigned long long *ep = h.data() + (size_t)68 * 4096;
       double both = 0, one = 0, period = 0, elen = 0;
       long np = 0;
       for (long w = 0; w < n_wg / 2; ++w) {
