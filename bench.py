@@ -371,7 +371,8 @@ def product_cpu_mode(pkg, synth, shapes, threads, budget_s):
     # The library's host threads inherit the affinity of the thread that starts them -- and this thread was pinned to ONE
     # core by the OpenMP runtime (OMP_PROC_BIND=close for the reference legs binds the initial thread when libgomp loads).
     # For this leg it gets back the mask the process started with (main() recorded it before anything loaded OpenMP);
-    # without that 16 pool threads shared one core (first r06 run: 230 images/s instead of the number below).
+    # without that 16 pool threads shared one core (first r06 run: 230 images/s).  Inside the mask the pool spreads itself
+    # (sconv_cpu.cpp, place_on_own_core): no warm-up second is needed for the scheduler to find the other cores.
     pinned = None
     if _ALLOWED_CPUS:
         try:
@@ -396,16 +397,17 @@ def _product_cpu_mode(pkg, synth, shapes, threads, per_image, share):
         b = synth.bias_vector(s, 2000 + k)
         n = min(256, max(16 * threads, 64))      # (whole-batch calls like the reference legs: 16 images per thread)
         x = synth.activations(s, 3000 + k, 0, n)
-        t0 = time.perf_counter()                                  # warm: threads, page faults, padded buffers -- and the
-        while time.perf_counter() - t0 < (1.5 if k == 0 else 0.2):   # scheduler: a VM host may take a second to spread a
-            plan.forward_cpu(x, b, n_threads=threads)             # freshly started team over the cores (the pool keeps it there)
+        top = np.zeros((n, s.M) + tuple(plan.out_hw), np.float32)   # the top blob exists before Forward (Reshape), as in Caffe
+        t0 = time.perf_counter()                                  # warm: threads, page faults, padded buffers
+        while time.perf_counter() - t0 < (0.5 if k == 0 else 0.2):
+            plan.forward_cpu(x, b, n_threads=threads, out=top)
         t0 = time.perf_counter()
-        plan.forward_cpu(x, b, n_threads=threads)
+        plan.forward_cpu(x, b, n_threads=threads, out=top)
         t1 = time.perf_counter() - t0
         reps = int(max(1, min(50, share / max(t1, 1e-4))))
         t0 = time.perf_counter()
         for _ in range(reps):
-            plan.forward_cpu(x, b, n_threads=threads)
+            plan.forward_cpu(x, b, n_threads=threads, out=top)
         t1 = (time.perf_counter() - t0) / reps
         per_image += s.count * t1 / n
         log("  cpu %-16s product  %4d threads %6d img in %.4f s -> %.1f img/s/layer" % (s.name, threads, n, t1, n / t1))

@@ -248,15 +248,21 @@ class Plan(object):
         fn = lib().escoin_weight_align_cpu_f64 if f64 else lib().escoin_weight_align_cpu
         check(fn(self._h, _np_ptr(w)), "escoin_weight_align_cpu")
 
-    def forward_cpu(self, bottom, bias=None, n_threads=0):
-        """Forward_cpu on numpy arrays (float32 or float64, matching the aligned weights)."""
+    def forward_cpu(self, bottom, bias=None, n_threads=0, out=None):
+        """Forward_cpu on numpy arrays (float32 or float64, matching the aligned weights).  `out`: a C-contiguous top
+        blob to write into (a Caffe top blob is allocated once at Reshape, not per Forward)."""
         d = self.desc
         f64 = bottom.dtype == np.float64
         dt = np.float64 if f64 else np.float32
         x = np.ascontiguousarray(bottom, dt)
         assert tuple(x.shape[1:]) == (d.C, d.H, d.W), "bottom shape mismatch"
         b = None if bias is None else np.ascontiguousarray(bias, dt)
-        top = np.empty((x.shape[0], d.M) + tuple(self.out_hw), dt)
+        shape = (x.shape[0], d.M) + tuple(self.out_hw)
+        if out is None:
+            top = np.empty(shape, dt)
+        else:
+            assert out.dtype == dt and tuple(out.shape) == shape and out.flags["C_CONTIGUOUS"], "out: wrong dtype / shape / layout"
+            top = out
         fn = lib().escoin_forward_cpu_f64 if f64 else lib().escoin_forward_cpu
         check(fn(self._h, _np_ptr(x), _np_ptr(b) if b is not None else None, _np_ptr(top), x.shape[0],
                  int(n_threads)), "escoin_forward_cpu")

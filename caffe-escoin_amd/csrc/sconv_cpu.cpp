@@ -28,6 +28,9 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include "escoin_plan.h"
 #include "sconv_cpu.h"
 
@@ -61,10 +64,10 @@ static void run_group(const GroupJob<T> &job) {
 }
 
 // The host threads of the CPU mode: one pool per process, grown on demand, its threads parked on a condition variable
-// between calls.  (Starting fresh std::threads per call was measured first: a new thread starts on its parent's core
-// and the scheduler spreads the team one thread per 4 ms tick -- a 40 ms forward then ran on little more than one core.
-// Parked threads stay where the balancer put them.)  One team job runs at a time; a second host thread calling in
-// waits for the pool (plans are thread-compatible, the pool is thread-safe).
+// between calls and placed on cores of their own when they start (place_on_own_core below).  (Starting fresh
+// std::threads per call was measured first: a new thread starts on its parent's core and the scheduler spread the team
+// one thread per 4 ms tick -- a 40 ms forward then ran on little more than one core.)  One team job runs at a time; a
+// second host thread calling in waits for the pool (plans are thread-compatible, the pool is thread-safe).
 class Pool {
  public:
   static Pool &get() {
@@ -137,7 +140,30 @@ class Pool {
       if (!job.first) job.first = std::current_exception();
     }
   }
+  // A new thread starts on its creator's core, and on the hosts measured (VM guests) a team parked there is woken there:
+  // the first second of calls ran eight threads on one core.  So a worker is PLACED when it starts -- moved to "its" core
+  // of the mask it inherited (worker id -> the (id + 1)-th allowed core, the caller keeps the first) and given the whole
+  // mask back at once: it stays where it was put because that is now the core it last ran on, and the scheduler is still
+  // free to move it.  Nothing is pinned (the reference binds its OpenMP threads for good, cpu_info.cpp:483-605).
+  static void place_on_own_core(int id) {
+    cpu_set_t inherited;
+    CPU_ZERO(&inherited);
+    if (pthread_getaffinity_np(pthread_self(), sizeof(inherited), &inherited) != 0) return;
+    const int n = CPU_COUNT(&inherited);
+    if (n < 2) return;
+    int want = (id + 1) % n, cpu = -1;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &inherited) && want-- == 0) { cpu = c; break; }
+    if (cpu < 0) return;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(cpu, &one);
+    if (pthread_setaffinity_np(pthread_self(), sizeof(one), &one) != 0) return;
+    sched_yield();                                                   // (runs on `cpu` from here)
+    pthread_setaffinity_np(pthread_self(), sizeof(inherited), &inherited);
+  }
   void worker_main(int id) {
+    place_on_own_core(id);
     unsigned long seen = 0;
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {

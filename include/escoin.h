@@ -330,7 +330,9 @@ ESCOIN_API int escoin_weight_align_cpu_f64(escoin_plan *plan, const double *dens
  * n_threads: host threads to use (<= 0: all the process may run on).  n_images is not bounded by desc.N.
  * The threads are a process-wide pool of parked std::threads, grown on demand; a new one inherits the CPU affinity of
  * the thread whose call started it (a caller pinned to one core -- e.g. by an OpenMP runtime's OMP_PROC_BIND -- gets
- * a pool pinned to that core: widen the mask around the first call if that is not wanted). */
+ * a pool pinned to that core: widen the mask around the first call if that is not wanted).  Inside that mask a worker
+ * moves itself to a core of its own when it starts and takes the whole mask back at once: the team is spread over the
+ * cores from the first call, and nothing stays bound (the scheduler may still move it). */
 ESCOIN_API int escoin_forward_cpu(escoin_plan *plan, const float *bottom, const float *bias, float *top, int n_images,
                        int n_threads);
 ESCOIN_API int escoin_forward_cpu_f64(escoin_plan *plan, const double *bottom, const double *bias, double *top,

@@ -233,6 +233,32 @@ def test_product_library_does_not_know_the_oracle(pkg):
                 assert "oracle" not in line, (fn, line)
 
 
+def test_pool_threads_are_placed_not_pinned_and_out_is_written_in_place(pkg, oracle, synth):
+    """The pool's workers are moved to a core of their own when they start and get the mask they inherited back at once
+    (sconv_cpu.cpp, place_on_own_core): after a team call every thread of the process still has the caller's mask.  And
+    `out=` writes the caller's top blob (a Caffe top is allocated at Reshape, not per Forward)."""
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_getaffinity on this platform")
+    s = synth.googlenet_1x1(N=8)[3]
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    w = synth.pruned_weights(s, 5)
+    plan.weight_align_cpu(w)
+    x = synth.activations(s, 6, 0, 8)
+    mine = os.sched_getaffinity(0)
+    top = np.full((8, s.M) + tuple(plan.out_hw), np.nan, np.float32)
+    got = plan.forward_cpu(x, None, n_threads=6, out=top)
+    assert got is top and not np.isnan(top).any()
+    assert np.array_equal(top, plan.forward_cpu(x, None, n_threads=1))
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            assert os.sched_getaffinity(int(tid)) == mine, "thread %s was left pinned" % tid
+        except ProcessLookupError:
+            pass
+    with pytest.raises(AssertionError):
+        plan.forward_cpu(x, None, out=top[:, :, ::-1])           # not C-contiguous
+    plan.close()
+
+
 @pytest.mark.parametrize("seed", [20261004, 7])
 def test_cpu_forward_seeded_random_geometries(pkg, oracle, seed):
     """A seeded slice of random geometries (kernel 1..5 per axis, strides 1..3, pads 0..3, dilation 1..2, groups, odd
