@@ -74,9 +74,10 @@ class HipBackend(object):
     name = "hip"
     dist_backend = "nccl"
 
-    def __init__(self, pkg, local_rank, kernel, stream_stores=False):
+    def __init__(self, pkg, local_rank, kernel, stream_stores=False, code_loader=0):
         import torch
         self.torch, self.pkg, self.kernel, self.stream_stores = torch, pkg, kernel, stream_stores
+        self.code_loader = code_loader
         if not torch.cuda.is_available() or pkg.device_count() < 1:
             raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
         # (one rank per GPU under the driver; ranks wrap around when a rehearsal runs more ranks than
@@ -87,6 +88,8 @@ class HipBackend(object):
 
     def make_plan(self, shape):
         opts = {"stream_stores": 1} if self.stream_stores else {}
+        if self.code_loader:
+            opts["code_loader"] = int(self.code_loader)
         return self.pkg.Plan(self.pkg.ConvDesc.from_shape(shape), kernel=self.kernel, **opts)
 
     def synchronize(self):
@@ -1058,6 +1061,9 @@ def parse_args(argv=None):
                     help="plan option stream_stores = 1: pointwise layers write their top blob with non-temporal "
                          "stores (the layers of a step have no consumer here; a net's next layer reads the blob, "
                          "and the default keeps it cached -- tools/producer_consumer.py)")
+    ap.add_argument("--code-loader", type=int, default=0, choices=[0, 1],
+                    help="plan option code_loader: 0 = generated code into executable device memory the library fills itself "
+                         "(default), 1 = through the HIP module loader (the fallback; for comparisons)")
     ap.add_argument("--broadcast", default="aligned", choices=["aligned", "csr"],
                     help="N > 1: what rank 0 broadcasts per layer -- the aligned form incl. the generated code (receivers "
                          "load it as it is), or the CSR alone (receivers run their own WeightAlign tail)")
@@ -1168,7 +1174,7 @@ def main(backend_factory=None, script=None):
         be = backend_factory(local_rank)
         args.dist_backend = be.dist_backend
     else:
-        be = HipBackend(pkg, local_rank, kernel, stream_stores=args.stream_stores)
+        be = HipBackend(pkg, local_rank, kernel, stream_stores=args.stream_stores, code_loader=args.code_loader)
     dist_on = world > 1 or args.force_dist
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -557,6 +557,11 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
       p->dense_threshold_pct = value;
       return ESCOIN_OK;
     }
+    if (!strcmp(key, "code_loader")) {
+      if (value < 0 || value > 1) return fail(ESCOIN_EINVAL, "code_loader must be 0 or 1");
+      p->code_loader = value;
+      return ESCOIN_OK;
+    }
     if (!strcmp(key, "stream_stores")) {
       if (value < -1 || value > 1) return fail(ESCOIN_EINVAL, "stream_stores must be -1, 0 or 1");
       p->stream_stores = value;
@@ -825,6 +830,7 @@ long escoin_plan_stat(const escoin_plan *p, const char *key) {
   if (!strcmp(key, "code_bytes")) return (long)(p->tiled.enabled && p->tiled.jit ? p->jit_module.code_bytes : 0);
   if (!strcmp(key, "device_bytes")) return (long)p->device_bytes;
   if (!strcmp(key, "import_fast")) return p->import_fast ? 1 : 0;
+  if (!strcmp(key, "code_direct")) return p->jit_module.direct ? 1 : 0;     // the plan's code sits in executable memory the library filled itself
   if (!strcmp(key, "small_launch_rule")) return p->small_rule;
   if (!strcmp(key, "jit_rows")) return p->tiled.jit ? p->tiled.jit_rows : 0;
   if (!strcmp(key, "jit_records")) return p->tiled.jit ? p->tiled.jit_records : 0;

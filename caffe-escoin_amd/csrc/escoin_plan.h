@@ -129,13 +129,14 @@ struct escoin_plan {
   escoin::TiledConfig tiled;
   unsigned *d_stream = nullptr;   // unit bodies of the weight stream (stream_builder.h)
   unsigned *d_unit_hdr = nullptr; // 8 dwords per (conv group, oc group, ic block); generated code: 1 (code offset)
-  escoin::JitModule jit_module;   // generated-code kernel: the loaded code object and where its code lives
+  escoin::JitModule jit_module;   // generated-code kernel: where the plan's code lives on the device (jit_module.h)
   unsigned *d_chan = nullptr;     // slot -> output channel (WeightStream::chan)
   size_t stream_words = 0;
   size_t tiled_device_bytes = 0;  // device bytes of the five members above (part of device_bytes)
   // host copies of what a generated-code plan loaded, kept for escoin_plan_export_aligned: the code
-  // object (ELF), the unit table and the channel deal
-  std::vector<char> jit_elf;
+  // (position-independent words, jit_codegen.h), the unit table and the channel deal
+  std::vector<uint32_t> jit_code;
+  int code_loader = 0;            // option "code_loader": 0 executable device memory first, 1 the code object loader (jit_module.h)
   std::vector<uint32_t> h_unit_off, h_chan;
   double align_ms = 0.0;          // wall time of the last weight_align / set_csr / import_aligned
   bool import_fast = false;       // the last import_aligned loaded a persisted code object as it was

@@ -5,12 +5,14 @@
 #include <elf.h>
 #include <unistd.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
 
+#include "code_memory.h"
 #include "escoin_plan.h"
 #include "knobs.h"
 
@@ -337,21 +339,51 @@ int jit_wrap(const std::vector<uint32_t> &code, std::vector<char> *elf) {
   return ESCOIN_OK;
 }
 
-int jit_load(const std::vector<uint32_t> &code, JitModule *out, hipStream_t stream, std::vector<char> *keep_elf) {
-  static const bool wrap = (ESC_KNOB("JIT_WRAP", 1) != 0);
-  std::vector<char> elf;
-  int rc = wrap ? jit_wrap(code, &elf) : ESCOIN_EHIP;
-  if (rc == ESCOIN_OK) rc = jit_load_elf(elf, code.size() * 4, out, stream);
-  if (rc != ESCOIN_OK) {       // (no template, or a loader that does not take the grown one: the assembler's own)
-    rc = jit_assemble(code, &elf);
-    if (rc == ESCOIN_OK) rc = jit_load_elf(elf, code.size() * 4, out, stream);
+// code -> executable device memory (code_memory.h): staged through an ordinary device buffer, copied by a kernel
+static int jit_load_direct(const uint32_t *code, size_t words, JitModule *out, hipStream_t stream) {
+  const size_t bytes = words * 4, total = (bytes + 256 + 4095) / 4096 * 4096;   // >= 64 s_nop behind the code, like the wrapper
+  void *exec = nullptr, *stage = nullptr;
+  int rc = code_mem_alloc(total, &exec);
+  if (rc != ESCOIN_OK) return rc;
+  hipError_t e = hipMalloc(&stage, bytes);
+  if (e == hipSuccess) e = hipMemcpyAsync(stage, code, bytes, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) rc = code_mem_fill(exec, stage, bytes, total, stream);
+  if (e == hipSuccess && rc == ESCOIN_OK) e = hipStreamSynchronize(stream);
+  if (stage) (void)hipFree(stage);
+  if (e != hipSuccess || rc != ESCOIN_OK) {
+    code_mem_free(exec);
+    return rc != ESCOIN_OK ? rc : fail(ESCOIN_EHIP, std::string("jit: filling the code memory failed: ") + hipGetErrorString(e));
   }
-  if (rc == ESCOIN_OK && keep_elf) keep_elf->swap(elf);
+  JitModule m;
+  m.direct = exec;
+  m.code_base = (unsigned long long)(uintptr_t)exec;
+  m.code_bytes = bytes;
+  *out = m;
+  return ESCOIN_OK;
+}
+
+int jit_load(const uint32_t *code, size_t words, JitModule *out, hipStream_t stream, int loader) {
+  if (!code || words == 0) return fail(ESCOIN_EINVAL, "jit: empty program");
+  static const bool direct_on = (ESC_KNOB("JIT_DIRECT", 1) != 0);
+  if (loader == 0 && direct_on) {
+    if (jit_load_direct(code, words, out, stream) == ESCOIN_OK) return ESCOIN_OK;
+    if (getenv("ESCOIN_VERBOSE")) fprintf(stderr, "[escoin] jit: no executable device memory (%s): the code object loader instead\n", escoin_last_error());
+  }
+  static const bool wrap = (ESC_KNOB("JIT_WRAP", 1) != 0);
+  const std::vector<uint32_t> words_v(code, code + words);
+  std::vector<char> elf;
+  int rc = wrap ? jit_wrap(words_v, &elf) : ESCOIN_EHIP;
+  if (rc == ESCOIN_OK) rc = jit_load_elf(elf, words * 4, out, stream);
+  if (rc != ESCOIN_OK) {       // (no template, or a loader that does not take the grown one: the assembler's own)
+    rc = jit_assemble(words_v, &elf);
+    if (rc == ESCOIN_OK) rc = jit_load_elf(elf, words * 4, out, stream);
+  }
   return rc;
 }
 
 void jit_unload(JitModule *m) {
   if (m && m->module) (void)hipModuleUnload(m->module);
+  if (m && m->direct) code_mem_free(m->direct);
   if (m) *m = JitModule();
 }
 

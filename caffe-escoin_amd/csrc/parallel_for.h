@@ -1,5 +1,6 @@
 // parallel_for.h -- WeightAlign's helper threads (channel deal, code generation): fn(i) for i = 0 .. n-1 on up to
 // n_threads threads, the caller among them, items handed out from a shared counter.
+//   * a helper moves itself to a core of its own when it starts (thread_place.h);
 //   * a thread the system refuses to create is simply one worker fewer;
 //   * an exception thrown by fn on ANY thread (std::bad_alloc from a growing code vector) stops the hand-out, is kept
 //     (the first one wins) and rethrown on the calling thread after every helper has been joined -- through an RAII
@@ -15,6 +16,8 @@
 #include <thread>
 #include <vector>
 
+#include "thread_place.h"
+
 namespace escoin {
 
 template <class F>
@@ -29,8 +32,9 @@ void parallel_for(size_t n_items, size_t n_threads, F &&fn) {
   std::atomic<bool> stop{false};
   std::exception_ptr first;
   std::mutex first_mu;
-  auto worker = [&]() {
+  auto worker = [&](int slot) {
     try {
+      if (slot > 0) place_on_own_core(slot);   // a helper starts on the caller's core otherwise (thread_place.h)
       for (size_t i = next.fetch_add(1); i < n_items && !stop.load(std::memory_order_relaxed); i = next.fetch_add(1)) fn(i);
     } catch (...) {
       stop.store(true);
@@ -47,10 +51,10 @@ void parallel_for(size_t n_items, size_t n_threads, F &&fn) {
   } pool;
   try {
     pool.t.reserve(n_threads - 1);
-    for (size_t th = 1; th < n_threads; ++th) pool.t.emplace_back(worker);
+    for (size_t th = 1; th < n_threads; ++th) pool.t.emplace_back(worker, (int)th);
   } catch (...) {   // std::system_error (no more threads) or std::bad_alloc: go on with the helpers that exist
   }
-  worker();
+  worker(0);
   for (auto &th : pool.t) th.join();
   pool.t.clear();
   if (first) std::rethrow_exception(first);

@@ -28,11 +28,9 @@
 #include <thread>
 #include <vector>
 
-#include <pthread.h>
-#include <sched.h>
-
 #include "escoin_plan.h"
 #include "sconv_cpu.h"
+#include "thread_place.h"
 
 namespace escoin {
 namespace cpu {
@@ -140,30 +138,9 @@ class Pool {
       if (!job.first) job.first = std::current_exception();
     }
   }
-  // A new thread starts on its creator's core, and on the hosts measured (VM guests) a team parked there is woken there:
-  // the first second of calls ran eight threads on one core.  So a worker is PLACED when it starts -- moved to "its" core
-  // of the mask it inherited (worker id -> the (id + 1)-th allowed core, the caller keeps the first) and given the whole
-  // mask back at once: it stays where it was put because that is now the core it last ran on, and the scheduler is still
-  // free to move it.  Nothing is pinned (the reference binds its OpenMP threads for good, cpu_info.cpp:483-605).
-  static void place_on_own_core(int id) {
-    cpu_set_t inherited;
-    CPU_ZERO(&inherited);
-    if (pthread_getaffinity_np(pthread_self(), sizeof(inherited), &inherited) != 0) return;
-    const int n = CPU_COUNT(&inherited);
-    if (n < 2) return;
-    int want = (id + 1) % n, cpu = -1;
-    for (int c = 0; c < CPU_SETSIZE; ++c)
-      if (CPU_ISSET(c, &inherited) && want-- == 0) { cpu = c; break; }
-    if (cpu < 0) return;
-    cpu_set_t one;
-    CPU_ZERO(&one);
-    CPU_SET(cpu, &one);
-    if (pthread_setaffinity_np(pthread_self(), sizeof(one), &one) != 0) return;
-    sched_yield();                                                   // (runs on `cpu` from here)
-    pthread_setaffinity_np(pthread_self(), sizeof(inherited), &inherited);
-  }
+  // (a worker is placed on a core of its own when it starts: thread_place.h; the caller keeps the mask's first core)
   void worker_main(int id) {
-    place_on_own_core(id);
+    place_on_own_core(id + 1);
     unsigned long seen = 0;
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {

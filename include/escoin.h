@@ -143,6 +143,11 @@ ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
  *   "max_launch_bytes" = bottom-blob bytes one launch of the LDS-tiled kernels may cover (0 = the 4 GiB range of
  *                  a buffer descriptor; larger batches run as consecutive sub-batch launches).  Results do not
  *                  depend on it; tests use it to exercise the sub-batch loop on small inputs.
+ *   "code_loader" = how WeightAlign / import_aligned put generated code on the device.  0 (default): executable
+ *                  device memory from the ROCm runtime's allocator, filled by a copy kernel (~0.1 ms per megabyte),
+ *                  and the code object loader where that is not to be had; 1: always the code object loader
+ *                  (hipModuleLoadData on the code wrapped in a code object, 0.6-1 ms per megabyte).  The code is the
+ *                  same words either way; tests use 1 to exercise the fallback.  stat "code_direct" says which.
  * Environment: the product build reads ESCOIN_VERBOSE (diagnostics on stderr) and TMPDIR (temporary file of the
  * code object manager's fallback path) and nothing else -- no environment variable can change a result
  * ("Environment"; csrc/knobs.h for the experiment flavours built by tools/mkabl.sh). */

@@ -1081,6 +1081,32 @@ def test_plan_churn_gives_its_device_memory_back(pkg, synth, torch_cuda):
     assert max(free[1:]) - min(free[1:]) <= 8 << 20, free
 
 
+def test_code_address_reuse_runs_the_new_code(pkg, oracle, synth, torch_cuda):
+    """Generated code lives in executable device memory the library fills itself (csrc/code_memory.h): a destroyed plan's
+    address range comes back for the next plan's code, and nothing but the kernel's own invalidation stands between that
+    plan and the previous tenant's instructions / weight lines in the CUs' caches (the first build of this path returned
+    NaN on exactly this pattern).  Same shape -- same code size, so the allocator hands the same range back --, other
+    weights every round, both code loaders, small and chip-filling batches: every round against the oracle."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    for s in (synth.shape("r14", 40, 40, 14, 14, 96, 1, sparsity=0.95, group=2),
+              synth.shape("r7k3", 24, 64, 7, 7, 64, 3, pad=1, sparsity=0.9, bias=False)):
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
+        x = synth.activations(s, 31)
+        xd = torch.from_numpy(x).to(dev)
+        for it in range(6):
+            w, b = synth.pruned_weights(s, 200 + it), synth.bias_vector(s, 300 + it)
+            plan = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256, code_loader=it % 3 == 2)
+            plan.weight_align(w)
+            assert plan.stat("code_direct") == (0 if it % 3 == 2 else 1)
+            bd = torch.from_numpy(b).to(dev) if b is not None else None
+            want = oracle.conv_forward(g, x, w, b, gate=False, threads=4)
+            for n in (s.N, 3):
+                got = plan.forward(xd[:n], bd).cpu().numpy()
+                assert rel_err(got, want[:n]) <= 1e-4, (s.name, it, n)
+            plan.close()
+
+
 def test_plans_of_two_host_threads_on_two_streams(pkg, oracle, synth, torch_cuda):
     """a layer instance belongs to one host thread; several threads, each with its own plans and its own
     stream, share the device.  Two threads WeightAlign (code generation, the process-wide code object template, module

@@ -41,12 +41,13 @@ def test_code_object_without_the_assembler_is_the_assemblers(tmp_path):
     import __graft_entry__ as ge
     ge.build()      # (the library's objects: the check links jit_module.o and what it refers to)
     objs = [os.path.join(CSRC, o) for o in ("jit_module.o", "escoin_capi.o", "sconv_generic.o", "sconv_tiled.o", "dense_mfma.o",
-                                            "sconv_lowered.o", "stream_builder.o", "jit_codegen.o")]
+                                            "sconv_lowered.o", "code_memory.o", "stream_builder.o", "jit_codegen.o", "sconv_cpu.o",
+                                            "sconv_cpu_kernel_avx2.o", "sconv_cpu_kernel_avx512.o")]
     assert all(os.path.exists(o) for o in objs)
     obj, exe = str(tmp_path / "jit_wrap_check.o"), str(tmp_path / "jit_wrap_check")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
                            "-I/opt/rocm/include", "-c", os.path.join(ROOT, "tests", "cpp", "jit_wrap_check.cpp"), "-o", obj])
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-o", exe, obj] + objs + ["-lamd_comgr"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-o", exe, obj] + objs + ["-lamd_comgr", "-lhsa-runtime64", "-lpthread"])
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = out.stdout.decode()
     assert out.returncode == 0 and "all cases OK" in text, text

@@ -146,7 +146,7 @@ def test_forward_is_capturable_in_a_hip_graph(pkg, oracle, synth):
 
 def test_export_import_aligned_round_trip(pkg, oracle, synth):
     """escoin_plan_export_aligned -> escoin_plan_import_aligned: a generated-code plan restored from the
-    persisted blob (CSR + channel deal + unit table + code object) loads the code object as it is, computes
+    persisted blob (CSR + channel deal + unit table + code) loads the code as it is, computes
     bit-identical outputs, and costs a fraction of WeightAlign; a blob for another batch / geometry falls back to
     aligning from its CSR; a damaged blob is refused."""
     import torch
@@ -214,7 +214,20 @@ def test_export_import_aligned_round_trip(pkg, oracle, synth):
         p4 = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256)
         assert p4.import_aligned(torch.from_numpy(blob).to(dev)) is True
         assert np.array_equal(p4.forward(x, bd).cpu().numpy(), want), s.name
-        for q in (plan, p2, p3, p4, other, plan_b):
+        # where the code lives (round 6): executable device memory the library fills itself is the default and must be
+        # what this box uses; option code_loader = 1 sends the same words through the HIP module loader -- same blob,
+        # same results, either way round between exporter and importer
+        assert plan.stat("code_direct") == 1 and p2.stat("code_direct") == 1 and p4.stat("code_direct") == 1
+        p5 = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256, code_loader=1)
+        p5.weight_align(w)
+        assert p5.stat("code_direct") == 0 and p5.stat("code_bytes") == plan.stat("code_bytes")
+        assert np.array_equal(p5.forward(x, bd).cpu().numpy(), want), s.name
+        assert np.array_equal(p5.export_aligned(), blob)
+        p6 = pkg.Plan(pkg.ConvDesc.from_shape(s), kernel=pkg.KERNEL_JIT, tiling_batch=256, code_loader=1)
+        assert p6.import_aligned(blob) is True and p6.stat("code_direct") == 0
+        assert np.array_equal(p6.forward(x, bd).cpu().numpy(), want), s.name
+        print("%s: weight_align %.1f ms direct / %.1f ms code object loader; import %.1f / %.1f ms" % (s.name, t_align, p5.align_ms, p2.align_ms, p6.align_ms))
+        for q in (plan, p2, p3, p4, p5, p6, other, plan_b):
             q.close()
     g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, group=s.group)
     ref = oracle.conv_forward(g, x.cpu().numpy(), w, b, gate=False)

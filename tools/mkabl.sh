@@ -21,7 +21,7 @@ O=/tmp/abl_$TAG
 mkdir -p $O ../../tools/ab
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-result -Wno-inline-asm -fvisibility=hidden -DESCOIN_BUILD $DEF ${ABL_CFLAGS:-}"
 pids=()
-for s in escoin_capi sconv_generic sconv_tiled dense_mfma sconv_lowered; do
+for s in escoin_capi sconv_generic sconv_tiled dense_mfma sconv_lowered code_memory; do
   /opt/rocm/bin/hipcc $F -c -o $O/$s.o $s.hip & pids+=($!)
 done
 for s in stream_builder jit_codegen jit_module; do
@@ -33,5 +33,5 @@ CPUF="-x c++ -O3 -std=c++17 -fPIC -fvisibility=hidden -DESCOIN_BUILD -ffp-contra
 /opt/rocm/bin/hipcc $CPUF -DESC_CPU_ISA=2 -mavx2 -mfma -c -o $O/sconv_cpu_kernel_avx2.o sconv_cpu_kernel.cpp & pids+=($!)
 /opt/rocm/bin/hipcc $CPUF -DESC_CPU_ISA=512 -mavx512f -mavx512vl -mavx512dq -mavx2 -mfma -c -o $O/sconv_cpu_kernel_avx512.o sconv_cpu_kernel.cpp & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done     # a failed compile aborts the script (set -e)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libescoin_$TAG.so $O/*.o -lamd_comgr -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libescoin_$TAG.so $O/*.o -lamd_comgr -lhsa-runtime64 -lpthread
 ls -la ../../tools/ab/libescoin_$TAG.so
