@@ -182,7 +182,7 @@ ESCOIN_API int escoin_plan_get_csr(const escoin_plan *plan, int *rowptr, int *co
 ESCOIN_API size_t escoin_plan_workspace_bytes(const escoin_plan *plan);
 
 /* The aligned form as one relocatable byte blob: the CSR and -- for a generated-code plan -- the
- * channel deal, the unit table and the code object WeightAlign produced.  The reference recomputes
+ * channel deal, the unit table and the machine code WeightAlign generated.  The reference recomputes
  * its aligned form on every weight load (Net::CopyTrainedLayersFrom -> WeightAlign, net.cpp:819);
  * here WeightAlign also compiles code (2-25 ms per layer since round 4, profiles/r04_weight_align.md), and a
  * deployment may persist the result once.
@@ -190,9 +190,9 @@ ESCOIN_API size_t escoin_plan_workspace_bytes(const escoin_plan *plan);
  *   import: restores the CSR (always) and, when the blob's code section was written by this library
  *           build for this geometry / batch / tiling_batch, for the same split of the conv groups between the
  *           sparse and the dense kernel (options dense_threshold_pct, dense_gate, conv_mode decide it) and on a
- *           device of the same ISA and CU count, loads the persisted code object as it is -- no channel deal, no generator pass, no assembler
+ *           device of the same ISA and CU count, puts the persisted code on the device as it is -- no channel deal, no generator pass, no assembler, no code object loader
  *           (escoin_plan_stat(plan, "import_fast") == 1); otherwise it aligns from the CSR like
- *           escoin_plan_set_csr -- also when the device refuses the persisted code object.  Plan options must be
+ *           escoin_plan_set_csr -- also when the persisted code cannot be placed on this device.  Plan options must be
  *           set before the import, as before weight_align.  Every field of the blob is range-checked before it
  *           sizes or indexes anything; a malformed blob gives ESCOIN_EINVAL, never a crash.  The header carries 64-bit
  *           content tags of the CSR section and of the code section and one binding the two: a blob whose code does not
