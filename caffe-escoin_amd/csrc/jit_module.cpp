@@ -383,7 +383,12 @@ int jit_load(const uint32_t *code, size_t words, JitModule *out, hipStream_t str
 
 void jit_unload(JitModule *m) {
   if (m && m->module) (void)hipModuleUnload(m->module);
-  if (m && m->direct) code_mem_free(m->direct);
+  if (m && m->direct) {
+    // (hipModuleUnload and hipFree wait for the device themselves; the runtime's allocator underneath does not, and a
+    //  launch that still runs this code may be in flight on a stream the caller has not synchronised)
+    (void)hipDeviceSynchronize();
+    code_mem_free(m->direct);
+  }
   if (m) *m = JitModule();
 }
 
