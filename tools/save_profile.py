@@ -18,6 +18,9 @@ import re
 import sys
 
 
+HELPER = re.compile(r"locator|code_copy|sk_clear")
+
+
 def short(name):
     name = re.sub(r"^void ", "", name)
     m = re.match(r"(escoin::)?(escoin_\w+(<[^>]*>)?)", name)
@@ -72,7 +75,7 @@ def main():
             for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
                 for fn in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
                     rows = [r for r in csv.DictReader(open(fn)) if r["Counter_Name"] == cname and short(r["Kernel_Name"]).startswith("escoin")
-                            and "locator" not in r["Kernel_Name"]]
+                            and not HELPER.search(r["Kernel_Name"])]
                     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
                     if len(rows) % len(order):
                         print("per-layer breakdown skipped: %d escoin dispatches are not whole steps of %d" % (len(rows), len(order)))
@@ -93,6 +96,8 @@ def main():
     workload = tag.split("_", 1)[1] if "_" in tag else tag
     traffic = {}
     for k, cs in summary.items():
+        if HELPER.search(k):      # (not a layer's launch: the locator / code copy of WeightAlign, stream-K's flag kernel)
+            continue
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             traffic[k] = int((2 * cs["FETCH_SIZE"]["per_launch"] + cs["WRITE_SIZE"]["per_launch"]) * 1024)
             traffic["_fetch_kib_per_launch"] = cs["FETCH_SIZE"]["per_launch"]
