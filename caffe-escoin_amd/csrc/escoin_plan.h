@@ -84,7 +84,7 @@ struct TiledConfig {
 
 // One host thread's buffers of the CPU mode (sconv_cpu.cpp): the shared-halo padded image and the store scratch.
 struct CpuWorkspace {
-  std::vector<char> pad, scratch;
+  std::vector<char> pad, scratch, partial;   // padded image, one tile for the stores, parked sums of channel blocking
   const void *src = nullptr;     // the bottom image the padded buffer currently holds ...
   unsigned long call = 0;        // ... as of this escoin_forward_cpu call
 };
@@ -117,6 +117,11 @@ struct escoin_plan {
   bool host_aligned = false;
   std::vector<std::vector<int>> cpu_off;
   bool cpu_off_valid = false;
+  // channel blocking of the CPU mode (sconv_cpu.h GroupJob::blk_ptr): per conv group, Mg x (cpu_blk_n + 1) nonzero indices
+  // for blocks of cpu_blk_cb input channels (-1: not built; 0: this geometry runs unblocked)
+  std::vector<std::vector<int>> cpu_blk;
+  int cpu_blk_cb = -1, cpu_blk_n = 0, cpu_blk_isa = 0, cpu_blk_elem = 0;
+  int cpu_blk_force = 0;          // option "cpu_channel_block": 0 = chosen from the geometry, > 0 = this many channels per block
   std::vector<escoin::CpuWorkspace> cpu_ws;   // per team thread: padded image + store scratch
   unsigned long cpu_calls = 0;
 

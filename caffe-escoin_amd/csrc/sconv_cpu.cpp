@@ -212,6 +212,45 @@ static void build_offsets(escoin_plan *p) {
     }
   }
   p->cpu_off_valid = true;
+  p->cpu_blk_cb = -1;
+}
+
+// The channel blocks of a stride-1 plan for the active flavour and element type (sconv_cpu.h): where every row's nonzeros
+// cross from one block of input channels to the next.  Built once per plan (again if the flavour is switched).
+template <typename T>
+static void build_channel_blocks(escoin_plan *p) {
+  const Geometry &g = p->g;
+  const escoin_conv_desc &d = g.d;
+  const int PW = d.W + d.pad_w;
+  long nnz = 0;
+  for (int grp = 0; grp < d.group; ++grp) nnz += (long)p->colidx[grp].size();
+  const double avg_row = (double)nnz / std::max(1, d.group * g.Mg);
+  int cb = 0;
+  if (d.stride_h == 1 && d.stride_w == 1)
+    cb = isa() == kAvx512 ? channel_block_avx512<T>(g.OH, g.OW, PW, (d.KH - 1) * d.dil_h, g.Cg, avg_row)
+                          : channel_block_avx2<T>(g.OH, g.OW, PW, (d.KH - 1) * d.dil_h, g.Cg, avg_row);
+  if (p->cpu_blk_force > 0 && d.stride_h == 1 && d.stride_w == 1) cb = p->cpu_blk_force >= g.Cg ? 0 : p->cpu_blk_force;
+  p->cpu_blk_isa = (int)isa();
+  p->cpu_blk_elem = (int)sizeof(T);
+  p->cpu_blk_cb = cb;
+  p->cpu_blk_n = cb > 0 ? (g.Cg + cb - 1) / cb : 0;
+  p->cpu_blk.assign(d.group, std::vector<int>());
+  if (cb <= 0) return;
+  const int nb = p->cpu_blk_n, taps = d.KH * d.KW;
+  for (int grp = 0; grp < d.group; ++grp) {
+    const std::vector<int> &rp = p->rowptr[grp], &ci = p->colidx[grp];
+    std::vector<int> &blk = p->cpu_blk[grp];
+    blk.resize((size_t)g.Mg * (nb + 1));
+    for (int m = 0; m < g.Mg; ++m) {
+      int j = rp[m];
+      for (int b = 0; b < nb; ++b) {
+        blk[(size_t)m * (nb + 1) + b] = j;
+        const int ic_end = (b + 1) * cb;                          // (ascending columns: ascending channels)
+        while (j < rp[m + 1] && ci[j] / taps < ic_end) ++j;
+      }
+      blk[(size_t)m * (nb + 1) + nb] = rp[m + 1];
+    }
+  }
 }
 
 template <typename T>
@@ -225,6 +264,7 @@ static int forward_cpu(escoin_plan *p, const T *bottom, const T *bias, T *top, i
   if (n_images == 0) return ESCOIN_OK;
   if (isa() == kNone) return fail(ESCOIN_ENODEVICE, "the CPU path needs AVX2 + FMA (the reference builds with -mavx2 -mfma too)");
   if (!p->cpu_off_valid) build_offsets(p);
+  if (p->cpu_blk_cb < 0 || p->cpu_blk_isa != (int)isa() || p->cpu_blk_elem != (int)sizeof(T)) build_channel_blocks<T>(p);
   const Geometry &g = p->g;
   const escoin_conv_desc &d = g.d;
   const int PH = d.H + d.pad_h, PW = d.W + d.pad_w;
@@ -246,6 +286,8 @@ static int forward_cpu(escoin_plan *p, const T *bottom, const T *bias, T *top, i
   if ((int)p->cpu_ws.size() < team_size) p->cpu_ws.resize((size_t)team_size);
   const size_t pad_bytes = padded ? (plen + kSlack) * sizeof(T) : 0;
   const size_t scratch_bytes = scratch_elems(g.OH, PW) * sizeof(T);
+  const bool blocked = p->cpu_blk_cb > 0 && p->cpu_blk_n > 1;
+  const size_t partial_bytes = blocked ? (size_t)((g.Mg + parts - 1) / parts + 1) * kPartialElemsPerRow * sizeof(T) : 0;
   team(team_size, n_items, [&](int tid, int item) {
     CpuWorkspace &L = p->cpu_ws[(size_t)tid];
     if (L.pad.size() != pad_bytes) {
@@ -253,6 +295,7 @@ static int forward_cpu(escoin_plan *p, const T *bottom, const T *bias, T *top, i
       L.src = nullptr;
     }
     if (L.scratch.size() < scratch_bytes) L.scratch.assign(scratch_bytes, 0);
+    if (L.partial.size() < partial_bytes) L.partial.assign(partial_bytes, 0);
     const int n = item / parts, part = item - n * parts;
     const T *image = bottom + (size_t)n * bottom_dim;
     const T *in_p = image;
@@ -284,6 +327,9 @@ static int forward_cpu(escoin_plan *p, const T *bottom, const T *bias, T *top, i
       J.relu = d.fuse_relu;
       J.exact_reads = padded ? 0 : 1;                             // an unpadded layer reads the caller's blob itself
       J.scratch = reinterpret_cast<T *>(L.scratch.data());
+      J.blk_ptr = blocked ? p->cpu_blk[grp].data() : nullptr;
+      J.n_blk = blocked ? p->cpu_blk_n : 0;
+      J.partial = blocked ? reinterpret_cast<T *>(L.partial.data()) : nullptr;
       run_group<T>(J);
     }
   });
@@ -336,6 +382,7 @@ static int cpu_sconv(const T *input_padded, int in_channels, int height, int wid
     J.m_end = (int)((long)out_channels * (part + 1) / n_threads);
     J.OH = OH; J.OW = OW; J.PW = PW; J.stride_h = stride_h; J.stride_w = stride_w; J.relu = 0; J.exact_reads = 1;
     J.scratch = sc.data();
+    J.blk_ptr = nullptr; J.n_blk = 0; J.partial = nullptr;      // (a one-off call on the caller's CSR: no block table to amortise)
     run_group<T>(J);
   });
   return ESCOIN_OK;

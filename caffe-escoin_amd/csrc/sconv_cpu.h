@@ -32,9 +32,24 @@ struct GroupJob {
   int exact_reads;      // 1: never read past the last input element an output needs (drop-in callers hand over
                         // buffers of exactly the reference's length); 0: a vector of slack follows the image
   T *scratch;           // >= scratch_len<T>(OH, PW, OW) elements, private to the calling thread
+  // Channel blocking (stride 1 only; the reference's register-blocked kernel does the same, sconv.hpp:57-589 "column
+  // blocking" with partial sums in scratch): a tile's input window of ALL channels does not fit L1 on the larger
+  // layers, so the channels go by in blocks -- block outer, output channel inner, the tile's partial sums of every
+  // output channel parked in `partial` between blocks.  A row's nonzeros are in ascending channel order, so block after
+  // block continues the same sum in the same order: results stay bit-identical.
+  const int *blk_ptr;   // nullptr = no blocking; else [m * (n_blk + 1) + b] = first nonzero of row m in channel block b
+  int n_blk;
+  T *partial;           // >= (m_end - m_begin) * partial_elems_per_row() elements, private to the calling thread
 };
 
 size_t scratch_elems(int OH, int PW);
+constexpr size_t kPartialElemsPerRow = 16 * 16;   // one tile of the widest flavour (14 vectors x 16 floats), rounded up
+
+// Input channels per block for this geometry in the named flavour, 0 = do not block.  span_rows = (KH - 1) * dil_h,
+// avg_row_nnz = nonzeros per output channel (a block with a handful of nonzeros per row costs more in parked sums than
+// it saves in L1 misses).
+template <typename T> int channel_block_avx2(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz);
+template <typename T> int channel_block_avx512(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz);
 
 // Runs one job.  Each output is sum = fma(val[j], in[...], sum) over the row's nonzeros in CSR order starting from
 // zero, then + bias, then ReLU -- lane for lane the arithmetic of caffe_cpu_sconv, so results are bit-identical to it

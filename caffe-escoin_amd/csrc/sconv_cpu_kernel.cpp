@@ -148,10 +148,70 @@ static void tile_unit_stride(const GroupJob<T> &J, int q0, int masked_n, const S
   }
 }
 
+// The same tile with the input channels going by in blocks (GroupJob::blk_ptr): block outer, output channel inner.
+template <typename T, int NV>
+static void tile_unit_stride_blocked(const GroupJob<T> &J, int q0, int masked_n, const Seg *segs, int nseg, bool direct,
+                                     int n_valid) {
+  typedef Vec<T> X;
+  typedef typename X::V V;
+  constexpr int L = X::L;
+  const T *base = J.in + q0;
+  const size_t plane = (size_t)J.OH * J.OW;
+  const int nb = J.n_blk;
+  for (int b = 0; b < nb; ++b) {
+    const bool first = b == 0, last = b == nb - 1;
+    for (int m = J.m_begin; m < J.m_end; ++m) {
+      const int jb = J.blk_ptr[(size_t)m * (nb + 1) + b], je = J.blk_ptr[(size_t)m * (nb + 1) + b + 1];
+      T *park = J.partial + (size_t)(m - J.m_begin) * kPartialElemsPerRow;
+      if (jb == je && !first && !last) continue;             // nothing of this row in this block: its sums stay parked
+      V acc[NV];
+      if (first) {
+        for (int t = 0; t < NV; ++t) acc[t] = X::zero();
+      } else {
+        for (int t = 0; t < NV; ++t) acc[t] = X::load(park + t * L);
+      }
+      if (masked_n == 0) {
+        for (int j = jb; j < je; ++j) {
+          const V v = X::bcast(J.val[j]);
+          const T *p = base + J.off[j];
+#pragma unroll
+          for (int t = 0; t < NV; ++t) acc[t] = X::fma(v, X::load(p + t * L), acc[t]);
+        }
+      } else {
+        for (int j = jb; j < je; ++j) {
+          const V v = X::bcast(J.val[j]);
+          const T *p = base + J.off[j];
+#pragma unroll
+          for (int t = 0; t < NV - 1; ++t) acc[t] = X::fma(v, X::load(p + t * L), acc[t]);
+          acc[NV - 1] = X::fma(v, X::load_n(p + (NV - 1) * L, masked_n), acc[NV - 1]);
+        }
+      }
+      if (!last) {
+        for (int t = 0; t < NV; ++t) X::store(park + t * L, acc[t]);
+        continue;
+      }
+      if (J.bias) {
+        const V bv = X::bcast(J.bias[m]);
+        for (int t = 0; t < NV; ++t) acc[t] = X::add(acc[t], bv);
+      }
+      if (J.relu)
+        for (int t = 0; t < NV; ++t) acc[t] = X::relu(acc[t]);
+      T *outp = J.out + (size_t)m * plane;
+      if (direct && n_valid == NV * L) {
+        for (int t = 0; t < NV; ++t) X::store(outp + q0 + t * L, acc[t]);
+      } else {
+        for (int t = 0; t < NV; ++t) X::store(J.scratch + t * L, acc[t]);
+        for (int s = 0; s < nseg; ++s) memcpy(outp + segs[s].dst, J.scratch + segs[s].src, sizeof(T) * (size_t)segs[s].len);
+      }
+    }
+  }
+}
+
 template <typename T, int NV>
 struct TileTable {
   static void fill(void (**tab)(const GroupJob<T> &, int, int, const Seg *, int, bool, int)) {
     tab[NV] = &tile_unit_stride<T, NV>;
+    tab[kMaxVecs + 1 + NV] = &tile_unit_stride_blocked<T, NV>;
     TileTable<T, NV - 1>::fill(tab);
   }
 };
@@ -165,8 +225,8 @@ static void run_unit_stride(const GroupJob<T> &J) {
   constexpr int L = Vec<T>::L;
   typedef void (*TileFn)(const GroupJob<T> &, int, int, const Seg *, int, bool, int);
   struct Table {
-    TileFn fn[kMaxVecs + 1];
-    Table() { fn[0] = nullptr; TileTable<T, kMaxVecs>::fill(fn); }
+    TileFn fn[2 * (kMaxVecs + 1)];       // [nv] = all channels at once, [kMaxVecs + 1 + nv] = channel blocks
+    Table() { fn[0] = fn[kMaxVecs + 1] = nullptr; TileTable<T, kMaxVecs>::fill(fn); }
   };
   static const Table table;   // (a function-local static: initialised once, thread-safe)
   const int Q = (J.OH - 1) * J.PW + J.OW;               // virtual pixels
@@ -195,7 +255,7 @@ static void run_unit_stride(const GroupJob<T> &J) {
     }
     const int tail = q1 - (q0 + (nv - 1) * L);           // valid lanes of the last vector, 1 .. L
     const int masked_n = (J.exact_reads && tail < L) ? tail : 0;
-    table.fn[nv](J, q0, masked_n, segs, nseg, direct, q1 - q0);
+    table.fn[(J.blk_ptr && J.n_blk > 1 ? kMaxVecs + 1 : 0) + nv](J, q0, masked_n, segs, nseg, direct, q1 - q0);
   }
 }
 
@@ -240,6 +300,25 @@ static void run_any_stride(const GroupJob<T> &J) {
   }
 }
 
+// Channels per block: as many as keep a tile's input window (rows the tile's pixels span + the kernel's rows, whole
+// padded rows) inside kL1Window bytes, but never so few that a row has fewer than ~kMinBlockNnz nonzeros per block.
+constexpr int kL1Window = 24 * 1024, kMinBlockNnz = 8;
+template <typename T>
+static int channel_block(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz) {
+  constexpr int L = Vec<T>::L;
+  if (OH < 1 || OW < 1 || PW < 1 || Cg < 2) return 0;
+  const int Q = (OH - 1) * PW + OW;
+  const int nvec = (Q + L - 1) / L;
+  const int ntiles = (nvec + kMaxVecs - 1) / kMaxVecs;
+  const int per_tile = (nvec + ntiles - 1) / ntiles;
+  const long rows = (long)(per_tile * L + PW - 1) / PW + 1 + span_rows;
+  const long per_channel = rows * PW * (long)sizeof(T);
+  if (per_channel * Cg <= kL1Window + kL1Window / 2) return 0;          // the whole window (nearly) fits as it is
+  long cb = std::max<long>(1, kL1Window / per_channel);
+  if (avg_row_nnz > 0) cb = std::max<long>(cb, (long)std::ceil((double)Cg * kMinBlockNnz / avg_row_nnz));
+  return cb >= Cg ? 0 : (int)cb;
+}
+
 template <typename T>
 static void run_group(const GroupJob<T> &J) {
   if (J.m_end <= J.m_begin || J.OH < 1 || J.OW < 1) return;
@@ -255,11 +334,21 @@ static void run_group(const GroupJob<T> &J) {
 template <typename T> void run_group_avx512(const GroupJob<T> &job) { run_group<T>(job); }
 template void run_group_avx512<float>(const GroupJob<float> &);
 template void run_group_avx512<double>(const GroupJob<double> &);
+template <typename T> int channel_block_avx512(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz) {
+  return channel_block<T>(OH, OW, PW, span_rows, Cg, avg_row_nnz);
+}
+template int channel_block_avx512<float>(int, int, int, int, int, double);
+template int channel_block_avx512<double>(int, int, int, int, int, double);
 #else
 size_t scratch_elems(int /*OH*/, int /*PW*/) { return 16 * 16; }   // one tile of the widest flavour (14 x 16 floats), rounded up
 template <typename T> void run_group_avx2(const GroupJob<T> &job) { run_group<T>(job); }
 template void run_group_avx2<float>(const GroupJob<float> &);
 template void run_group_avx2<double>(const GroupJob<double> &);
+template <typename T> int channel_block_avx2(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz) {
+  return channel_block<T>(OH, OW, PW, span_rows, Cg, avg_row_nnz);
+}
+template int channel_block_avx2<float>(int, int, int, int, int, double);
+template int channel_block_avx2<double>(int, int, int, int, int, double);
 #endif
 
 }  // namespace cpu

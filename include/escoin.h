@@ -118,7 +118,7 @@ ESCOIN_API long escoin_padded_len(const escoin_conv_desc *desc);
 ESCOIN_API int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan);
 ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
 
-/* Options (all but "conv_mode" must precede weight_align / set_csr):
+/* Options (all but "conv_mode" and "cpu_channel_block" must precede weight_align / set_csr):
  *   "kernel"     = ESCOIN_KERNEL_*;
  *   "conv_mode"  = Caffe::ConvMode (common.hpp:112; tools/caffe.cpp:292-301 -conv_mode N):
  *                  SCONV / SCONV_PAR = the direct sparse path (the two differ only in the
@@ -143,6 +143,10 @@ ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
  *   "max_launch_bytes" = bottom-blob bytes one launch of the LDS-tiled kernels may cover (0 = the 4 GiB range of
  *                  a buffer descriptor; larger batches run as consecutive sub-batch launches).  Results do not
  *                  depend on it; tests use it to exercise the sub-batch loop on small inputs.
+ *   "cpu_channel_block" = input channels per block of escoin_forward_cpu's channel blocking (0 = chosen from the
+ *                  geometry so that a tile's input window stays in L1; stride-1 layers only).  Results do not depend on
+ *                  it (a row's sum continues across blocks in CSR order); tests use it to block small inputs.  May be set
+ *                  on an aligned plan; stat "cpu_channel_block" = what the last escoin_forward_cpu used.
  *   "code_loader" = how WeightAlign / import_aligned put generated code on the device.  0 (default): executable
  *                  device memory from the ROCm runtime's allocator, filled by a copy kernel (~0.1 ms per megabyte),
  *                  and the code object loader where that is not to be had; 1: always the code object loader

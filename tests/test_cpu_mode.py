@@ -233,6 +233,54 @@ def test_product_library_does_not_know_the_oracle(pkg):
                 assert "oracle" not in line, (fn, line)
 
 
+def test_channel_blocking_keeps_every_bit(pkg, oracle, synth):
+    """Channel blocking (sconv_cpu.h GroupJob::blk_ptr; the reference's register-blocked kernel parks partial sums the same
+    way, sconv.hpp:57-589): the full-size layers pick a block size by themselves, and any forced block size on small and
+    awkward geometries -- one channel per block, blocks that leave rows empty, groups, dilation, masked tails, fewer
+    images than threads -- gives the bits of the unblocked run and of the oracle."""
+    # (1) the BASELINE shapes block by themselves where a tile's window exceeds L1
+    for s, expect_blocked in ((synth.resnet50_3x3(N=2)[0], True), (synth.resnet50_3x3(N=2)[2], True), (synth.lenet_conv2(N=2)[0], False)):
+        plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+        w, b = synth.pruned_weights(s, 3), synth.bias_vector(s, 4)
+        plan.weight_align_cpu(w)
+        x = synth.activations(s, 5, 0, 2)
+        got = plan.forward_cpu(x, b, n_threads=2)
+        assert (plan.stat("cpu_channel_block") > 0) == expect_blocked, (s.name, plan.stat("cpu_channel_block"))
+        plan.set_option("cpu_channel_block", 10 ** 6)            # more channels than the layer has: unblocked
+        assert np.array_equal(plan.forward_cpu(x, b, n_threads=2), got) and plan.stat("cpu_channel_block") == 0
+        g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, s.stride_h, s.stride_w, s.dil_h, s.dil_w, s.group)
+        assert np.array_equal(got, oracle.conv_forward(g, x, w, b, gate=False, threads=4)), s.name
+        plan.close()
+    # (2) forced block sizes on small geometries
+    rng = np.random.RandomState(11)
+    for (C_, H, W, M, KH, KW, ph, pw, dh, dw, grp) in ((12, 9, 11, 7, 3, 3, 1, 1, 1, 1, 1), (16, 6, 5, 10, 1, 1, 0, 0, 1, 1, 2),
+                                                       (9, 13, 17, 6, 3, 2, 2, 3, 2, 1, 3), (20, 7, 7, 5, 5, 5, 2, 2, 1, 1, 1),
+                                                       (6, 30, 33, 4, 3, 3, 0, 1, 1, 2, 1)):
+        for dtype in (np.float32, np.float64):
+            Cg = C_ // grp
+            x = rng.uniform(-1, 1, (3, C_, H, W)).astype(dtype)
+            w = (rng.uniform(-1, 1, (M * grp, Cg, KH, KW)) * (rng.uniform(size=(M * grp, Cg, KH, KW)) < 0.35)).astype(dtype)
+            w[0] = 0                                                   # an empty row
+            b = rng.uniform(-0.1, 0.1, M * grp).astype(dtype)
+            g = oracle.geom(C_, H, W, M * grp, KH, KW, ph, pw, 1, 1, dh, dw, grp)
+            fwd = oracle.conv_forward_f64 if dtype == np.float64 else oracle.conv_forward
+            want = fwd(g, x, w, b) if dtype == np.float64 else fwd(g, x, w, b, gate=False)
+            desc = pkg.ConvDesc(N=3, C=C_, H=H, W=W, M=M * grp, KH=KH, KW=KW, pad_h=ph, pad_w=pw, stride_h=1, stride_w=1,
+                                dil_h=dh, dil_w=dw, group=grp, has_bias=1, fuse_relu=0)
+            plan = pkg.Plan(desc)
+            plan.weight_align_cpu(w)
+            for cb in (0, 1, 2, 3, Cg - 1, Cg):
+                if cb < 0:
+                    continue
+                plan.set_option("cpu_channel_block", cb)
+                for threads in (1, 5):
+                    got = plan.forward_cpu(x, b, n_threads=threads)
+                    assert np.array_equal(got, want), (C_, H, W, M, KH, KW, grp, dtype.__name__, cb, threads)
+                if 0 < cb < Cg:
+                    assert plan.stat("cpu_channel_block") == cb
+            plan.close()
+
+
 def test_pool_threads_are_placed_not_pinned_and_out_is_written_in_place(pkg, oracle, synth):
     """The pool's workers are moved to a core of their own when they start and get the mask they inherited back at once
     (sconv_cpu.cpp, place_on_own_core): after a team call every thread of the process still has the caller's mask.  And

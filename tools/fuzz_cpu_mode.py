@@ -12,6 +12,8 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     pkg, oracle = ge.load_package(), ge.load_oracle()
+    if len(sys.argv) > 3:
+        pkg.cpu_kernel_select(sys.argv[3])                         # "avx2" | "avx512" | "auto"
     rng = np.random.RandomState(seed)
     done = bad = 0
     while done < cases:
@@ -38,8 +40,12 @@ def main():
         want = fwd(g, x, w, b, relu=relu, gate=False)
         plan = pkg.Plan(pkg.ConvDesc(N, C_, H, W, M, KH, KW, ph, pw, sh, sw, dh, dw, grp, int(b is not None), int(relu)))
         plan.weight_align_cpu(w)
+        cb = int(rng.choice([0, 0, 1, 2, 3, 5]))                  # channels per block forced on half the cases (round 6)
+        if cb:
+            plan.set_option("cpu_channel_block", cb)
         got = plan.forward_cpu(x, b, n_threads=nt)
         if not np.array_equal(got, want):
+            print("(cpu_channel_block = %d)" % cb)
             bad += 1
             print("MISMATCH", dict(N=N, C=C_, H=H, W=W, M=M, KH=KH, KW=KW, ph=ph, pw=pw, sh=sh, sw=sw, dh=dh, dw=dw, grp=grp,
                                    dtype=dtype.__name__, relu=relu, bias=b is not None, threads=nt), flush=True)
