@@ -300,9 +300,12 @@ static void run_any_stride(const GroupJob<T> &J) {
   }
 }
 
-// Channels per block: as many as keep a tile's input window (rows the tile's pixels span + the kernel's rows, whole
-// padded rows) inside kL1Window bytes, but never so few that a row has fewer than ~kMinBlockNnz nonzeros per block.
-constexpr int kL1Window = 24 * 1024, kMinBlockNnz = 8;
+// Channels per block: as many as keep a tile's input window (the rows the tile's pixels span + the kernel's rows, whole
+// padded rows) inside kL1Window bytes, in blocks of equal size -- and none at all where a row would then have fewer than
+// kMinBlockNnz nonzeros per block: parking and fetching a tile's sums is 2 x NV vector moves per (row, block), and a
+// 95 %-sparse pointwise layer touches so few channels per row that nothing is reused between rows anyway (GoogLeNet's
+// 1x1 layers measured -10..-25 % with blocking forced on them; ResNet / AlexNet shapes +3..+80 % by CPU).
+constexpr int kL1Window = 24 * 1024, kMinBlockNnz = 12;
 template <typename T>
 static int channel_block(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz) {
   constexpr int L = Vec<T>::L;
@@ -313,10 +316,11 @@ static int channel_block(int OH, int OW, int PW, int span_rows, int Cg, double a
   const int per_tile = (nvec + ntiles - 1) / ntiles;
   const long rows = (long)(per_tile * L + PW - 1) / PW + 1 + span_rows;
   const long per_channel = rows * PW * (long)sizeof(T);
-  if (per_channel * Cg <= kL1Window + kL1Window / 2) return 0;          // the whole window (nearly) fits as it is
-  long cb = std::max<long>(1, kL1Window / per_channel);
-  if (avg_row_nnz > 0) cb = std::max<long>(cb, (long)std::ceil((double)Cg * kMinBlockNnz / avg_row_nnz));
-  return cb >= Cg ? 0 : (int)cb;
+  if (per_channel * Cg <= 2 * kL1Window) return 0;                     // the whole window (nearly) fits as it is
+  const long cb_l1 = std::max<long>(1, kL1Window / per_channel);
+  if (cb_l1 >= Cg || avg_row_nnz * (double)cb_l1 / Cg < kMinBlockNnz) return 0;
+  const long n_blk = (Cg + cb_l1 - 1) / cb_l1;
+  return (int)((Cg + n_blk - 1) / n_blk);
 }
 
 template <typename T>
