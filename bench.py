@@ -133,6 +133,11 @@ def layer_weight_seed(lid):
 
 
 def build_layers(be, pkg, synth, shapes, rank, world, args=None, dist_on=None):
+    with _unpinned():      # (WeightAlign's and the import's helper threads: see _unpinned)
+        return _build_layers(be, pkg, synth, shapes, rank, world, args, dist_on)
+
+
+def _build_layers(be, pkg, synth, shapes, rank, world, args=None, dist_on=None):
     """WeightAlign on rank 0, broadcast of the CSR (RCCL on the GPU box), set_csr elsewhere.
     Returns [(shape, plan, bias, shape_index, layer_id)] and the one-time costs: seconds in the
     broadcast, per-layer WeightAlign milliseconds (rank 0: dense -> CSR -> tiling, channel deal,
@@ -367,6 +372,33 @@ _HOST_INFO = None
 _ALLOWED_CPUS = None      # the affinity mask the process started with (main(), before any OpenMP runtime pinned this thread)
 
 
+class _unpinned(object):
+    """Gives this thread the affinity mask the process started with for the duration of a `with` block.
+    bench.py exports OMP_PROC_BIND=close for its reference CPU legs, and the OpenMP runtime torch loads binds the
+    INITIAL thread to one core when it loads; every thread the product library starts from this thread -- WeightAlign's
+    helpers (channel deal, code generation), the CPU mode's pool -- inherits that one-core mask.  That is this harness's
+    doing, not the deployment's: a Caffe process does not pin its main thread.  Without the block WeightAlign of a res5
+    layer measured 30 ms here against 17 ms in a plain process (profiles/r06_code_memory.md)."""
+
+    def __enter__(self):
+        self.pinned = None
+        if _ALLOWED_CPUS:
+            try:
+                self.pinned = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, _ALLOWED_CPUS)
+            except (AttributeError, OSError):
+                self.pinned = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.pinned:
+            try:
+                os.sched_setaffinity(0, self.pinned)
+            except OSError:
+                pass
+        return False
+
+
 def product_cpu_mode(pkg, synth, shapes, threads, budget_s):
     """The PRODUCT's own Caffe::CPU mode (escoin_forward_cpu, csrc/sconv_cpu*.cpp -- not the oracle, not oracle/_ref)
     on the same shapes and host cores, reported beside the reference CPU numbers: images/s over the whole layer set."""
@@ -376,21 +408,8 @@ def product_cpu_mode(pkg, synth, shapes, threads, budget_s):
     # For this leg it gets back the mask the process started with (main() recorded it before anything loaded OpenMP);
     # without that 16 pool threads shared one core (first r06 run: 230 images/s).  Inside the mask the pool spreads itself
     # (sconv_cpu.cpp, place_on_own_core): no warm-up second is needed for the scheduler to find the other cores.
-    pinned = None
-    if _ALLOWED_CPUS:
-        try:
-            pinned = os.sched_getaffinity(0)
-            os.sched_setaffinity(0, _ALLOWED_CPUS)
-        except (AttributeError, OSError):
-            pinned = None
-    try:
+    with _unpinned():
         return _product_cpu_mode(pkg, synth, shapes, threads, per_image, share)
-    finally:
-        if pinned:
-            try:
-                os.sched_setaffinity(0, pinned)
-            except OSError:
-                pass
 
 
 def _product_cpu_mode(pkg, synth, shapes, threads, per_image, share):
