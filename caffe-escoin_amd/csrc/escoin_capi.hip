@@ -540,7 +540,7 @@ int escoin_plan_destroy(escoin_plan *plan) {
 int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
   return guarded([&]() -> int {
     if (!p || !key) return fail(ESCOIN_EINVAL, "null argument");
-    if (p->aligned && strcmp(key, "conv_mode") != 0 && strcmp(key, "cpu_channel_block") != 0)
+    if (p->aligned && strcmp(key, "conv_mode") != 0 && strcmp(key, "cpu_channel_block") != 0 && strcmp(key, "cpu_images_per_job") != 0)
       return fail(ESCOIN_ESTATE, "this option must be set before weight_align/set_csr");
     if (!strcmp(key, "tiling_batch")) {
       if (value < 0) return fail(ESCOIN_EINVAL, "tiling_batch must be >= 0");
@@ -555,6 +555,11 @@ int escoin_plan_set_option(escoin_plan *p, const char *key, int value) {
     if (!strcmp(key, "dense_threshold_pct")) {
       if (value < -1 || value > 100) return fail(ESCOIN_EINVAL, "dense_threshold_pct must be in [-1, 100]");
       p->dense_threshold_pct = value;
+      return ESCOIN_OK;
+    }
+    if (!strcmp(key, "cpu_images_per_job")) {
+      if (value < 0) return fail(ESCOIN_EINVAL, "cpu_images_per_job must be >= 0");
+      p->cpu_img_force = value;
       return ESCOIN_OK;
     }
     if (!strcmp(key, "cpu_channel_block")) {
@@ -836,6 +841,7 @@ long escoin_plan_stat(const escoin_plan *p, const char *key) {
   if (!strcmp(key, "code_bytes")) return (long)(p->tiled.enabled && p->tiled.jit ? p->jit_module.code_bytes : 0);
   if (!strcmp(key, "device_bytes")) return (long)p->device_bytes;
   if (!strcmp(key, "import_fast")) return p->import_fast ? 1 : 0;
+  if (!strcmp(key, "cpu_images_per_job")) return p->cpu_img_last;   // images per job of the last escoin_forward_cpu
   if (!strcmp(key, "cpu_channel_block")) return p->cpu_blk_cb;     // channels per block of the last escoin_forward_cpu (0: unblocked, -1: none yet)
   if (!strcmp(key, "code_direct")) return p->jit_module.direct ? 1 : 0;     // the plan's code sits in executable memory the library filled itself
   if (!strcmp(key, "small_launch_rule")) return p->small_rule;

@@ -121,6 +121,8 @@ struct escoin_plan {
   // for blocks of cpu_blk_cb input channels (-1: not built; 0: this geometry runs unblocked)
   std::vector<std::vector<int>> cpu_blk;
   int cpu_blk_cb = -1, cpu_blk_n = 0, cpu_blk_isa = 0, cpu_blk_elem = 0;
+  int cpu_img_force = 0;          // option "cpu_images_per_job": 0 = chosen from the geometry, n = at most n images per job
+  int cpu_img_last = 0;           // what the last escoin_forward_cpu used
   int cpu_blk_force = 0;          // option "cpu_channel_block": 0 = chosen from the geometry, > 0 = this many channels per block
   std::vector<escoin::CpuWorkspace> cpu_ws;   // per team thread: padded image + store scratch
   unsigned long cpu_calls = 0;

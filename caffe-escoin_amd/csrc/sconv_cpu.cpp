@@ -274,17 +274,35 @@ static int forward_cpu(escoin_plan *p, const T *bottom, const T *bias, T *top, i
   const auto &values = plan_values<T>(p);
   n_threads = resolve_threads(n_threads);
   const unsigned long call_id = ++p->cpu_calls;   // the same blob pointer in a later call holds other data
-  // fewer images than threads: split every image's output channels too
+  // small images travel two or three to a job (sconv_cpu.h GroupJob::n_img) -- as long as every thread still gets one
+  int ni = isa() == kAvx512 ? images_per_job_avx512<T>(g.OH, g.OW, PW, d.stride_h, d.stride_w)
+                            : images_per_job_avx2<T>(g.OH, g.OW, PW, d.stride_h, d.stride_w);
+  {
+    // ... and only where their windows stay close to the core: with channel blocks they do by construction; without
+    // (the 95 %-sparse pointwise layers: few nonzeros per row, nothing to block for) three images' planes of every
+    // channel are three times the L2 traffic (GoogLeNet's 7 x 7 layers measured -13..-27 % with three images a job)
+    const bool will_block = p->cpu_blk_cb > 0 && p->cpu_blk_n > 1;
+    const long one = isa() == kAvx512 ? window_bytes_avx512<T>(g.OH, g.OW, PW, (d.KH - 1) * d.dil_h)
+                                      : window_bytes_avx2<T>(g.OH, g.OW, PW, (d.KH - 1) * d.dil_h);
+    constexpr long kNearBytes = 192 * 1024;
+    while (!will_block && ni > 1 && one * g.Cg * ni > kNearBytes) --ni;
+  }
+  if (p->cpu_img_force > 0) ni = std::min(ni, p->cpu_img_force);
+  ni = std::max(1, std::min(ni, n_images / std::max(1, n_threads)));
+  p->cpu_img_last = ni;
+  const int n_jobs = (n_images + ni - 1) / ni;
+  // fewer jobs than threads: split every job's output channels too
   int parts = 1;
-  if (n_images < n_threads) parts = std::min(g.Mg, (n_threads + n_images - 1) / n_images);
-  const int n_items = n_images * parts;
+  if (n_jobs < n_threads) parts = std::min(g.Mg, (n_threads + n_jobs - 1) / n_jobs);
+  const int n_items = n_jobs * parts;
   const int team_size = std::min(n_threads, n_items);
   constexpr size_t kSlack = 16;   // one vector behind the image: the kernel loads whole vectors at the image's end
   // per-thread padded buffer + store scratch, kept in the plan between calls (a plan belongs to one host thread at a
   // time, like a Caffe layer instance); zeroed when (re)allocated -- base_conv_layer.cpp:78-80 -- and only the interior
   // is ever rewritten
   if ((int)p->cpu_ws.size() < team_size) p->cpu_ws.resize((size_t)team_size);
-  const size_t pad_bytes = padded ? (plen + kSlack) * sizeof(T) : 0;
+  const size_t pad_elems = plen + kSlack;                          // one image's slot in a thread's padded buffer
+  const size_t pad_bytes = padded ? pad_elems * (size_t)ni * sizeof(T) : 0;
   const size_t scratch_bytes = scratch_elems(g.OH, PW) * sizeof(T);
   const bool blocked = p->cpu_blk_cb > 0 && p->cpu_blk_n > 1;
   const size_t partial_bytes = blocked ? (size_t)((g.Mg + parts - 1) / parts + 1) * kPartialElemsPerRow * sizeof(T) : 0;
@@ -296,16 +314,18 @@ static int forward_cpu(escoin_plan *p, const T *bottom, const T *bias, T *top, i
     }
     if (L.scratch.size() < scratch_bytes) L.scratch.assign(scratch_bytes, 0);
     if (L.partial.size() < partial_bytes) L.partial.assign(partial_bytes, 0);
-    const int n = item / parts, part = item - n * parts;
+    const int job = item / parts, part = item - job * parts;
+    const int n = job * ni, n_here = std::min(ni, n_images - n);     // images n .. n + n_here - 1
     const T *image = bottom + (size_t)n * bottom_dim;
     const T *in_p = image;
     if (padded) {
       T *pad = reinterpret_cast<T *>(L.pad.data());
-      if (L.src != (const void *)image || L.call != call_id) {     // (a thread pads an image once for all its channel slices)
-        for (int c = 0; c < d.C; ++c)                             // base_conv_layer.cpp:615-620
-          for (int r = 0; r < d.H; ++r)
-            memcpy(pad + ((size_t)c * PH + r + d.pad_h) * PW + d.pad_w, image + ((size_t)c * d.H + r) * d.W,
-                   sizeof(T) * (size_t)d.W);
+      if (L.src != (const void *)image || L.call != call_id) {     // (a thread pads its images once for all their channel slices)
+        for (int i = 0; i < n_here; ++i)
+          for (int c = 0; c < d.C; ++c)                           // base_conv_layer.cpp:615-620
+            for (int r = 0; r < d.H; ++r)
+              memcpy(pad + (size_t)i * pad_elems + ((size_t)c * PH + r + d.pad_h) * PW + d.pad_w,
+                     image + (size_t)i * bottom_dim + ((size_t)c * d.H + r) * d.W, sizeof(T) * (size_t)d.W);
         L.src = image;
         L.call = call_id;
       }
@@ -330,6 +350,9 @@ static int forward_cpu(escoin_plan *p, const T *bottom, const T *bias, T *top, i
       J.blk_ptr = blocked ? p->cpu_blk[grp].data() : nullptr;
       J.n_blk = blocked ? p->cpu_blk_n : 0;
       J.partial = blocked ? reinterpret_cast<T *>(L.partial.data()) : nullptr;
+      J.n_img = n_here;
+      J.in_stride = padded ? pad_elems : bottom_dim;
+      J.out_stride = top_dim;
       run_group<T>(J);
     }
   });
@@ -383,6 +406,7 @@ static int cpu_sconv(const T *input_padded, int in_channels, int height, int wid
     J.OH = OH; J.OW = OW; J.PW = PW; J.stride_h = stride_h; J.stride_w = stride_w; J.relu = 0; J.exact_reads = 1;
     J.scratch = sc.data();
     J.blk_ptr = nullptr; J.n_blk = 0; J.partial = nullptr;      // (a one-off call on the caller's CSR: no block table to amortise)
+    J.n_img = 1; J.in_stride = 0; J.out_stride = 0;
     run_group<T>(J);
   });
   return ESCOIN_OK;

@@ -40,6 +40,11 @@ struct GroupJob {
   const int *blk_ptr;   // nullptr = no blocking; else [m * (n_blk + 1) + b] = first nonzero of row m in channel block b
   int n_blk;
   T *partial;           // >= (m_end - m_begin) * partial_elems_per_row() elements, private to the calling thread
+  // Several images per job (small images only, images_per_job below): image i reads in + i * in_stride and writes
+  // out + i * out_stride.  A 7 x 7 image is four vectors -- four independent multiply-adds per nonzero against a
+  // latency of four cycles on two pipes -- so two or three images share every broadcast weight and fill the registers.
+  int n_img;            // 1 .. images_per_job
+  size_t in_stride, out_stride;
 };
 
 size_t scratch_elems(int OH, int PW);
@@ -48,6 +53,12 @@ constexpr size_t kPartialElemsPerRow = 16 * 16;   // one tile of the widest flav
 // Input channels per block for this geometry in the named flavour, 0 = do not block.  span_rows = (KH - 1) * dil_h,
 // avg_row_nnz = nonzeros per output channel (a block with a handful of nonzeros per row costs more in parked sums than
 // it saves in L1 misses).
+// Images a job should carry for this geometry in the named flavour (1 = one at a time).
+template <typename T> int images_per_job_avx2(int OH, int OW, int PW, int stride_h, int stride_w);
+template <typename T> int images_per_job_avx512(int OH, int OW, int PW, int stride_h, int stride_w);
+// Bytes of ONE channel of a tile's input window for one image (whole padded rows the tile's pixels span + the kernel's).
+template <typename T> long window_bytes_avx2(int OH, int OW, int PW, int span_rows);
+template <typename T> long window_bytes_avx512(int OH, int OW, int PW, int span_rows);
 template <typename T> int channel_block_avx2(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz);
 template <typename T> int channel_block_avx512(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz);
 

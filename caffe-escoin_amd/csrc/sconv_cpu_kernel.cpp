@@ -207,6 +207,103 @@ static void tile_unit_stride_blocked(const GroupJob<T> &J, int q0, int masked_n,
   }
 }
 
+// NI small images at once (each one tile of NV vectors starting at virtual pixel 0), with or without channel blocks:
+// one broadcast per nonzero feeds NI x NV multiply-adds.  Per output the arithmetic is what the single-image tile does.
+template <typename T, int NV, int NI>
+static void tile_multi(const GroupJob<T> &J, int masked_n, const Seg *segs, int nseg, bool direct, int n_valid) {
+  typedef Vec<T> X;
+  typedef typename X::V V;
+  constexpr int L = X::L;
+  const size_t plane = (size_t)J.OH * J.OW;
+  const bool blocked = J.blk_ptr && J.n_blk > 1;
+  const int nb = blocked ? J.n_blk : 1;
+  const T *ins[NI];
+  for (int i = 0; i < NI; ++i) ins[i] = J.in + (size_t)i * J.in_stride;
+  for (int b = 0; b < nb; ++b) {
+    const bool first = b == 0, last = b == nb - 1;
+    for (int m = J.m_begin; m < J.m_end; ++m) {
+      const int jb = blocked ? J.blk_ptr[(size_t)m * (nb + 1) + b] : J.rowptr[m];
+      const int je = blocked ? J.blk_ptr[(size_t)m * (nb + 1) + b + 1] : J.rowptr[m + 1];
+      T *park = blocked ? J.partial + (size_t)(m - J.m_begin) * kPartialElemsPerRow : nullptr;
+      if (jb == je && !first && !last) continue;
+      V acc[NI * NV];
+      if (first) {
+        for (int k = 0; k < NI * NV; ++k) acc[k] = X::zero();
+      } else {
+        for (int k = 0; k < NI * NV; ++k) acc[k] = X::load(park + k * L);
+      }
+      if (masked_n == 0) {
+        for (int j = jb; j < je; ++j) {
+          const V v = X::bcast(J.val[j]);
+          const int o = J.off[j];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const T *p = ins[i] + o;
+#pragma unroll
+            for (int t = 0; t < NV; ++t) acc[i * NV + t] = X::fma(v, X::load(p + t * L), acc[i * NV + t]);
+          }
+        }
+      } else {
+        for (int j = jb; j < je; ++j) {
+          const V v = X::bcast(J.val[j]);
+          const int o = J.off[j];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const T *p = ins[i] + o;
+#pragma unroll
+            for (int t = 0; t < NV - 1; ++t) acc[i * NV + t] = X::fma(v, X::load(p + t * L), acc[i * NV + t]);
+            acc[i * NV + NV - 1] = X::fma(v, X::load_n(p + (NV - 1) * L, masked_n), acc[i * NV + NV - 1]);
+          }
+        }
+      }
+      if (!last) {
+        for (int k = 0; k < NI * NV; ++k) X::store(park + k * L, acc[k]);
+        continue;
+      }
+      if (J.bias) {
+        const V bv = X::bcast(J.bias[m]);
+        for (int k = 0; k < NI * NV; ++k) acc[k] = X::add(acc[k], bv);
+      }
+      if (J.relu)
+        for (int k = 0; k < NI * NV; ++k) acc[k] = X::relu(acc[k]);
+      for (int i = 0; i < NI; ++i) {
+        T *outp = J.out + (size_t)i * J.out_stride + (size_t)m * plane;
+        if (direct && n_valid == NV * L) {
+          for (int t = 0; t < NV; ++t) X::store(outp + t * L, acc[i * NV + t]);
+        } else {
+          for (int t = 0; t < NV; ++t) X::store(J.scratch + t * L, acc[i * NV + t]);
+          for (int s = 0; s < nseg; ++s) memcpy(outp + segs[s].dst, J.scratch + segs[s].src, sizeof(T) * (size_t)segs[s].len);
+        }
+      }
+    }
+  }
+}
+
+constexpr int kMaxImages = 3;                 // images per job at most
+template <typename T> struct MultiTable {
+  typedef void (*Fn)(const GroupJob<T> &, int, const Seg *, int, bool, int);
+  Fn fn[kMaxImages + 1][kMaxVecs / 2 + 1];
+  MultiTable() {
+    for (auto &row : fn) for (auto &f : row) f = nullptr;
+#define ESC_MULTI(NV) fn[2][NV] = &tile_multi<T, NV, 2>; if (3 * NV <= kMaxVecs) fn[3][NV] = &tile_multi<T, NV, (3 * NV <= kMaxVecs ? 3 : 2)>;
+    ESC_MULTI(1) ESC_MULTI(2) ESC_MULTI(3) ESC_MULTI(4) ESC_MULTI(5) ESC_MULTI(6)
+#if ESC_CPU_ISA == 512
+    ESC_MULTI(7)
+#endif
+#undef ESC_MULTI
+  }
+};
+
+template <typename T>
+static int images_per_job(int OH, int OW, int PW, int stride_h, int stride_w) {
+  constexpr int L = Vec<T>::L;
+  if (stride_h != 1 || stride_w != 1 || OH < 1 || OW < 1) return 1;
+  const int Q = (OH - 1) * PW + OW;
+  const int nvec = (Q + L - 1) / L;
+  if (2 * nvec > kMaxVecs) return 1;
+  return std::min(kMaxImages, kMaxVecs / nvec);
+}
+
 template <typename T, int NV>
 struct TileTable {
   static void fill(void (**tab)(const GroupJob<T> &, int, int, const Seg *, int, bool, int)) {
@@ -231,6 +328,16 @@ static void run_unit_stride(const GroupJob<T> &J) {
   static const Table table;   // (a function-local static: initialised once, thread-safe)
   const int Q = (J.OH - 1) * J.PW + J.OW;               // virtual pixels
   const int nvec = (Q + L - 1) / L;
+  if (J.n_img > 1 && (J.n_img > kMaxImages || J.n_img * nvec > kMaxVecs)) {      // (more images than fit: one after the other)
+    GroupJob<T> one = J;
+    one.n_img = 1;
+    for (int i = 0; i < J.n_img; ++i) {
+      one.in = J.in + (size_t)i * J.in_stride;
+      one.out = J.out + (size_t)i * J.out_stride;
+      run_unit_stride<T>(one);
+    }
+    return;
+  }
   const int ntiles = (nvec + kMaxVecs - 1) / kMaxVecs;
   const int per_tile = (nvec + ntiles - 1) / ntiles;     // evenly sized tiles (14 x 14: 7 + 7 vectors, not 12 + 2)
   const bool direct = J.PW == J.OW;                      // no dropped columns: virtual pixel == output index
@@ -255,7 +362,12 @@ static void run_unit_stride(const GroupJob<T> &J) {
     }
     const int tail = q1 - (q0 + (nv - 1) * L);           // valid lanes of the last vector, 1 .. L
     const int masked_n = (J.exact_reads && tail < L) ? tail : 0;
-    table.fn[(J.blk_ptr && J.n_blk > 1 ? kMaxVecs + 1 : 0) + nv](J, q0, masked_n, segs, nseg, direct, q1 - q0);
+    if (J.n_img > 1) {
+      static const MultiTable<T> multi;
+      multi.fn[J.n_img][nv](J, masked_n, segs, nseg, direct, q1 - q0);     // (one tile per image: q0 = 0)
+    } else {
+      table.fn[(J.blk_ptr && J.n_blk > 1 ? kMaxVecs + 1 : 0) + nv](J, q0, masked_n, segs, nseg, direct, q1 - q0);
+    }
   }
 }
 
@@ -307,15 +419,20 @@ static void run_any_stride(const GroupJob<T> &J) {
 // 1x1 layers measured -10..-25 % with blocking forced on them; ResNet / AlexNet shapes +3..+80 % by CPU).
 constexpr int kL1Window = 24 * 1024, kMinBlockNnz = 12;
 template <typename T>
-static int channel_block(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz) {
+static long window_bytes(int OH, int OW, int PW, int span_rows) {
   constexpr int L = Vec<T>::L;
-  if (OH < 1 || OW < 1 || PW < 1 || Cg < 2) return 0;
+  if (OH < 1 || OW < 1 || PW < 1) return 0;
   const int Q = (OH - 1) * PW + OW;
   const int nvec = (Q + L - 1) / L;
   const int ntiles = (nvec + kMaxVecs - 1) / kMaxVecs;
   const int per_tile = (nvec + ntiles - 1) / ntiles;
   const long rows = (long)(per_tile * L + PW - 1) / PW + 1 + span_rows;
-  const long per_channel = rows * PW * (long)sizeof(T);
+  return rows * PW * (long)sizeof(T);
+}
+template <typename T>
+static int channel_block(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz) {
+  if (OH < 1 || OW < 1 || PW < 1 || Cg < 2) return 0;
+  const long per_channel = window_bytes<T>(OH, OW, PW, span_rows) * images_per_job<T>(OH, OW, PW, 1, 1);
   if (per_channel * Cg <= 2 * kL1Window) return 0;                     // the whole window (nearly) fits as it is
   const long cb_l1 = std::max<long>(1, kL1Window / per_channel);
   if (cb_l1 >= Cg || avg_row_nnz * (double)cb_l1 / Cg < kMinBlockNnz) return 0;
@@ -326,10 +443,17 @@ static int channel_block(int OH, int OW, int PW, int span_rows, int Cg, double a
 template <typename T>
 static void run_group(const GroupJob<T> &J) {
   if (J.m_end <= J.m_begin || J.OH < 1 || J.OW < 1) return;
-  if (J.stride_h == 1 && J.stride_w == 1)
+  if (J.stride_h == 1 && J.stride_w == 1) {
     run_unit_stride<T>(J);
-  else
-    run_any_stride<T>(J);
+  } else {
+    GroupJob<T> one = J;
+    one.n_img = 1;
+    for (int i = 0; i < std::max(1, J.n_img); ++i) {
+      one.in = J.in + (size_t)i * J.in_stride;
+      one.out = J.out + (size_t)i * J.out_stride;
+      run_any_stride<T>(one);
+    }
+  }
 }
 
 }  // namespace
@@ -338,6 +462,14 @@ static void run_group(const GroupJob<T> &J) {
 template <typename T> void run_group_avx512(const GroupJob<T> &job) { run_group<T>(job); }
 template void run_group_avx512<float>(const GroupJob<float> &);
 template void run_group_avx512<double>(const GroupJob<double> &);
+template <typename T> int images_per_job_avx512(int OH, int OW, int PW, int stride_h, int stride_w) {
+  return images_per_job<T>(OH, OW, PW, stride_h, stride_w);
+}
+template int images_per_job_avx512<float>(int, int, int, int, int);
+template int images_per_job_avx512<double>(int, int, int, int, int);
+template <typename T> long window_bytes_avx512(int OH, int OW, int PW, int span_rows) { return window_bytes<T>(OH, OW, PW, span_rows); }
+template long window_bytes_avx512<float>(int, int, int, int);
+template long window_bytes_avx512<double>(int, int, int, int);
 template <typename T> int channel_block_avx512(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz) {
   return channel_block<T>(OH, OW, PW, span_rows, Cg, avg_row_nnz);
 }
@@ -348,6 +480,14 @@ size_t scratch_elems(int /*OH*/, int /*PW*/) { return 16 * 16; }   // one tile o
 template <typename T> void run_group_avx2(const GroupJob<T> &job) { run_group<T>(job); }
 template void run_group_avx2<float>(const GroupJob<float> &);
 template void run_group_avx2<double>(const GroupJob<double> &);
+template <typename T> int images_per_job_avx2(int OH, int OW, int PW, int stride_h, int stride_w) {
+  return images_per_job<T>(OH, OW, PW, stride_h, stride_w);
+}
+template int images_per_job_avx2<float>(int, int, int, int, int);
+template int images_per_job_avx2<double>(int, int, int, int, int);
+template <typename T> long window_bytes_avx2(int OH, int OW, int PW, int span_rows) { return window_bytes<T>(OH, OW, PW, span_rows); }
+template long window_bytes_avx2<float>(int, int, int, int);
+template long window_bytes_avx2<double>(int, int, int, int);
 template <typename T> int channel_block_avx2(int OH, int OW, int PW, int span_rows, int Cg, double avg_row_nnz) {
   return channel_block<T>(OH, OW, PW, span_rows, Cg, avg_row_nnz);
 }

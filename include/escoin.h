@@ -118,7 +118,7 @@ ESCOIN_API long escoin_padded_len(const escoin_conv_desc *desc);
 ESCOIN_API int escoin_plan_create(const escoin_conv_desc *desc, escoin_plan **plan);
 ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
 
-/* Options (all but "conv_mode" and "cpu_channel_block" must precede weight_align / set_csr):
+/* Options (all but "conv_mode", "cpu_channel_block" and "cpu_images_per_job" must precede weight_align / set_csr):
  *   "kernel"     = ESCOIN_KERNEL_*;
  *   "conv_mode"  = Caffe::ConvMode (common.hpp:112; tools/caffe.cpp:292-301 -conv_mode N):
  *                  SCONV / SCONV_PAR = the direct sparse path (the two differ only in the
@@ -147,6 +147,9 @@ ESCOIN_API int escoin_plan_destroy(escoin_plan *plan);
  *                  geometry so that a tile's input window stays in L1; stride-1 layers only).  Results do not depend on
  *                  it (a row's sum continues across blocks in CSR order); tests use it to block small inputs.  May be set
  *                  on an aligned plan; stat "cpu_channel_block" = what the last escoin_forward_cpu used.
+ *   "cpu_images_per_job" = escoin_forward_cpu runs small images (a few vectors each: 7 x 7, 4 x 4, LeNet's 8 x 8) two or three
+ *                  to a job, one broadcast weight feeding every image's accumulators; 0 = chosen from the geometry,
+ *                  n = at most n.  Results do not depend on it; tests use it.  May be set on an aligned plan.
  *   "code_loader" = how WeightAlign / import_aligned put generated code on the device.  0 (default): executable
  *                  device memory from the ROCm runtime's allocator, filled by a copy kernel (~0.1 ms per megabyte),
  *                  and the code object loader where that is not to be had; 1: always the code object loader

@@ -281,6 +281,57 @@ def test_channel_blocking_keeps_every_bit(pkg, oracle, synth):
             plan.close()
 
 
+def test_several_small_images_per_job_keep_every_bit(pkg, oracle, synth):
+    """Small images travel two or three to a job (sconv_cpu.h GroupJob::n_img: one broadcast weight feeds every image's
+    accumulators): forced 1 / 2 / 3 images per job on 7 x 7, 4 x 4 and 5 x 9 geometries -- padded and not, groups, dilation,
+    with forced channel blocks, batches that are not a multiple of the group, fewer images than threads -- give the bits of
+    the oracle; and the full-size res5 shape takes three by itself."""
+    s = synth.resnet50_3x3(N=12)[3]
+    plan = pkg.Plan(pkg.ConvDesc.from_shape(s))
+    w = synth.pruned_weights(s, 3)
+    plan.weight_align_cpu(w)
+    x = synth.activations(s, 5, 0, 12)
+    got = plan.forward_cpu(x, None, n_threads=2)
+    # (seven 8-lane vectors per 7 x 7 image leave no room for a second image in the AVX2 flavour's twelve accumulators)
+    assert plan.stat("cpu_images_per_job") >= (2 if pkg.cpu_kernel_name().endswith("avx512") else 1) and plan.stat("cpu_channel_block") > 0
+    plan.set_option("cpu_images_per_job", 1)
+    assert np.array_equal(plan.forward_cpu(x, None, n_threads=2), got) and plan.stat("cpu_images_per_job") == 1
+    g = oracle.geom(s.C, s.H, s.W, s.M, s.KH, s.KW, s.pad_h, s.pad_w, 1, 1, 1, 1, s.group)
+    assert np.array_equal(got, oracle.conv_forward(g, x, w, None, gate=False, threads=4))
+    plan.close()
+    rng = np.random.RandomState(13)
+    for (C_, H, W, M, KH, KW, ph, pw, dh, dw, grp) in ((10, 7, 7, 6, 3, 3, 1, 1, 1, 1, 1), (12, 4, 4, 9, 1, 1, 0, 0, 1, 1, 3),
+                                                       (8, 5, 9, 5, 3, 3, 2, 0, 1, 2, 2), (16, 7, 7, 4, 1, 1, 0, 0, 1, 1, 1)):
+        for dtype in (np.float32, np.float64):
+            Cg = C_ // grp
+            N = 11
+            x = rng.uniform(-1, 1, (N, C_, H, W)).astype(dtype)
+            w = (rng.uniform(-1, 1, (M * grp, Cg, KH, KW)) * (rng.uniform(size=(M * grp, Cg, KH, KW)) < 0.4)).astype(dtype)
+            b = rng.uniform(-0.1, 0.1, M * grp).astype(dtype)
+            g = oracle.geom(C_, H, W, M * grp, KH, KW, ph, pw, 1, 1, dh, dw, grp)
+            want = oracle.conv_forward_f64(g, x, w, b) if dtype == np.float64 else oracle.conv_forward(g, x, w, b, gate=False)
+            desc = pkg.ConvDesc(N=N, C=C_, H=H, W=W, M=M * grp, KH=KH, KW=KW, pad_h=ph, pad_w=pw, stride_h=1, stride_w=1,
+                                dil_h=dh, dil_w=dw, group=grp, has_bias=1, fuse_relu=0)
+            plan = pkg.Plan(desc)
+            plan.weight_align_cpu(w)
+            seen = set()
+            for ni in (0, 1, 2, 3):
+                for cb in (0, 2):
+                    plan.set_option("cpu_images_per_job", ni)
+                    plan.set_option("cpu_channel_block", cb)
+                    for threads, n in ((1, N), (2, N), (4, 5), (16, 3)):
+                        got = plan.forward_cpu(x[:n], b, n_threads=threads)
+                        assert np.array_equal(got, want[:n]), (C_, H, W, M, KH, KW, grp, dtype.__name__, ni, cb, threads, n)
+                        seen.add(plan.stat("cpu_images_per_job"))
+            # (the multi-image tiles really ran wherever two images fit the flavour's accumulators)
+            wide = pkg.cpu_kernel_name().endswith("avx512")
+            lanes = (16 if wide else 8) // (2 if dtype == np.float64 else 1)
+            OH, OW = H + 2 * ph - (dh * (KH - 1) + 1) + 1, W + 2 * pw - (dw * (KW - 1) + 1) + 1
+            vecs = -(-((OH - 1) * (W + pw) + OW) // lanes)
+            assert (max(seen) >= 2) == (2 * vecs <= (14 if wide else 12)), (seen, vecs, lanes)
+            plan.close()
+
+
 def test_pool_threads_are_placed_not_pinned_and_out_is_written_in_place(pkg, oracle, synth):
     """The pool's workers are moved to a core of their own when they start and get the mask they inherited back at once
     (sconv_cpu.cpp, place_on_own_core): after a team call every thread of the process still has the caller's mask.  And

@@ -43,6 +43,7 @@ def main():
         cb = int(rng.choice([0, 0, 1, 2, 3, 5]))                  # channels per block forced on half the cases (round 6)
         if cb:
             plan.set_option("cpu_channel_block", cb)
+        plan.set_option("cpu_images_per_job", int(rng.choice([0, 0, 1, 2, 3])))   # small images: one, two or three to a job
         got = plan.forward_cpu(x, b, n_threads=nt)
         if not np.array_equal(got, want):
             print("(cpu_channel_block = %d)" % cb)
