@@ -213,7 +213,9 @@ ESCOIN_API int escoin_plan_import_aligned_dev(escoin_plan *plan, const void *dev
 
 /* Integer facts about an aligned plan (negative = error): "align_us" wall time of the last
  * weight_align / set_csr / import_aligned, "code_bytes" generated machine code on the device,
- * "device_bytes", "import_fast", "jit_rows", "jit_records", "lds_bytes", "workgroup_columns",
+ * "device_bytes", "import_fast", "code_direct" (1: the plan's generated code sits in executable device memory the library
+ * filled itself, 0: in a module the HIP loader loaded -- option "code_loader"), "cpu_channel_block" / "cpu_images_per_job"
+ * (what the last escoin_forward_cpu used), "jit_rows", "jit_records", "lds_bytes", "workgroup_columns",
  * "kernel_choice" (the ESCOIN_KERNEL_* id AUTO resolved to for the sparse groups), "small_launch_rule" (KERNEL_AUTO's
  * rule for pointwise launches under 64 MFLOP that fit one round of workgroups -- the reference's SCONV mode runs
  * image by image, conv_layer.cu:16-26 --: 0 not considered, 1 kept generated code, 2 took the generic kernel (decided
