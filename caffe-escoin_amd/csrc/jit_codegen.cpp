@@ -467,7 +467,7 @@ static Program build_pass(const ConvGeom &g, const Tiling &t, const std::vector<
   };
   size_t nnz = 0;
   for (const auto &c : colidx) nnz += c.size();
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t hw = (size_t)allowed_cores();     // (the cores this thread may use, not the machine's: thread_place.h)
   const size_t n_thr = nnz >= 20000 && n_chains > 1 ? std::min<size_t>(std::min<size_t>(8, hw), n_chains) : 1;
   // (parallel_for.h: the calling thread works too, a thread the system refuses is one worker fewer, an exception on
   //  any thread -- a code vector that cannot grow -- is rethrown here after the helpers were joined)

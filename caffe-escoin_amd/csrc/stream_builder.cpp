@@ -452,12 +452,12 @@ std::vector<uint32_t> balance_channels(const ConvGeom &g, const Tiling &t, const
   }
   };
   // WeightAlign is host time the caller waits for (res5: 70 ms of channel deal in one thread): the columns are
-  // independent, so large layers deal them on up to eight threads.  Deterministic: a column's result does not
+  // independent, so large layers deal them on up to eight threads (sixteen measured no faster).  Deterministic: a column's result does not
   // depend on the others'.
   std::vector<int> cols;
   for (int blk0 = 0; blk0 < n_ocg; blk0 += t.oc_waves) cols.push_back(blk0);
   const size_t work = (size_t)Mg * nb * words;
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t hw = (size_t)allowed_cores();     // (the cores this thread may use, not the machine's: thread_place.h)
   const size_t n_thr = work >= 4096 && cols.size() > 1 ? std::min<size_t>(std::min<size_t>(8, hw), cols.size()) : 1;
   // (parallel_for.h: the calling thread works too, a thread the system refuses is one worker fewer, an exception on
   //  any thread is rethrown here after the helpers were joined)

@@ -13,6 +13,15 @@
 
 namespace escoin {
 
+// Cores the calling thread may run on (its affinity mask; at least 1): how many helpers are worth starting.
+inline int allowed_cores() {
+  cpu_set_t mask;
+  CPU_ZERO(&mask);
+  if (pthread_getaffinity_np(pthread_self(), sizeof(mask), &mask) != 0) return 1;
+  const int n = CPU_COUNT(&mask);
+  return n > 0 ? n : 1;
+}
+
 inline void place_on_own_core(int slot) {
   cpu_set_t inherited;
   CPU_ZERO(&inherited);
